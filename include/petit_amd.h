@@ -1,0 +1,166 @@
+/*
+ * petit_amd.h -- C ABI of libpetit_amd.so, the MI355X (gfx950) build of the
+ * petit FP4 mixed-precision GEMM.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types, no
+ * C++ in the signatures.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree, causalflow-ai/petit-kernel
+ * v0.0.3).  The C++ namespace API of the reference
+ * (lib/gemm/rocm/quantization/gemm.h:119-146) is provided as inline wrappers
+ * over these symbols in include/causalflow/petit/gemm.h; the Python surface
+ * (petit_kernel/__init__.py:8-79) binds them through ctypes.
+ *
+ * Ownership: the caller owns every buffer; the library keeps no pointers past
+ * the call except the optional workspace registered with
+ * petit_set_workspace().  All work is enqueued on `stream` (a hipStream_t);
+ * nothing synchronises the host, so every call is HIP-graph capturable.
+ * Thread safety: all entry points may be called concurrently from several
+ * host threads; petit_set_workspace() is per-device state and must not race
+ * with GEMM calls on the same device.
+ */
+#ifndef PETIT_AMD_H_
+#define PETIT_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Return codes.  0/1/2 are the reference's (quantization/gemm.h:107-108):
+ * kErrorProblemShape = 1, kErrorKernelShape = 2.  3 and 4 are additions: the
+ * reference never polls launch errors (gemm_fp4_fp16_grid.cuh:556-559). */
+#define PETIT_OK 0
+#define PETIT_ERROR_PROBLEM_SHAPE 1
+#define PETIT_ERROR_KERNEL_SHAPE 2
+#define PETIT_ERROR_LAUNCH 3
+#define PETIT_ERROR_BAD_ARGUMENT 4
+
+/* Element types, numbered as the reference's C++ enum
+ * (quantization/types.h:4-13).  NOTE: the reference's *Python* DataType enum
+ * (petit_kernel/__init__.py:8-15) is numbered differently; the Python layer
+ * of this build translates. */
+typedef enum petit_data_type {
+    PETIT_DTYPE_INT4 = 0,
+    PETIT_DTYPE_FP8_E4M3 = 1,
+    PETIT_DTYPE_FP8_E8M0 = 2,
+    PETIT_DTYPE_FP4_E2M1 = 3, /* NVFP4: e4m3 scales, group 16 */
+    PETIT_DTYPE_FP16 = 4,
+    PETIT_DTYPE_BF16 = 5,
+    PETIT_DTYPE_FP8_E5M2_FNUZ = 6,
+    PETIT_DTYPE_MXFP4_E2M1 = 7 /* MXFP4: e8m0 scales, group 32 */
+} petit_data_type;
+
+/* PetitSolutionHints, quantization/gemm.h:112-117.  Ignored when an explicit
+ * solution id is passed.  require_high_precision is accepted for
+ * compatibility: every gfx950 kernel here dequantises exactly, so it never
+ * changes the result. */
+typedef struct petit_solution_hints {
+    int32_t a_type; /* PETIT_DTYPE_FP16 or PETIT_DTYPE_BF16 */
+    int32_t b_type; /* PETIT_DTYPE_FP4_E2M1 or PETIT_DTYPE_MXFP4_E2M1 */
+    int32_t c_type; /* must equal a_type */
+    int32_t require_high_precision;
+} petit_solution_hints;
+
+/* "Let the library choose": the reference's (unsigned long)-1 sentinel,
+ * fp4/gemm_fp4_fp16_grid.cc:46-48. */
+#define PETIT_SOLUTION_AUTO UINT64_MAX
+
+/*
+ * c[m][n] = a[m][k] . dequant(b)[n][k]^T * (*global_scale), f32 accumulate,
+ * one round-to-nearest-even to the 16-bit output type.
+ *   replaces fp4::GemmFp4Fp16Grid      quantization/gemm.h:120-124
+ *            (impl fp4/gemm_fp4_fp16_grid.cc:36-77)
+ *   c, a          device, row-major 16-bit (hints->a_type); a is [m][k]
+ *   b             device, packed weights from petit_repack_nvfp4_weights
+ *   scales        device, packed scales from petit_repack_nvfp4_scales
+ *   global_scale  DEVICE pointer to one float (lib/pybind/fp4.cc:198)
+ *   n % 16 == 0, k % 256 == 0, m arbitrary; m|n|k == 0 returns PETIT_OK
+ *   solution_id   PETIT_SOLUTION_AUTO or an id from petit_gemm_get_solutions
+ */
+int petit_gemm_fp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b,
+                             const unsigned *scales, const float *global_scale,
+                             unsigned m, unsigned n, unsigned k,
+                             const petit_solution_hints *hints,
+                             uint64_t solution_id, void *stream);
+
+/* Same for MXFP4 weights (e8m0 scales, group 32).
+ *   replaces fp4::GemmMxFp4Fp16Grid    quantization/gemm.h:126-130
+ *            (impl fp4/gemm_fp4_fp16_grid.cc:79-95)
+ * The reference accepts bf16 activations only (gemm_fp4_fp16_grid.cc:55-64);
+ * this build also accepts fp16. */
+int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b,
+                               const unsigned *scales, const float *global_scale,
+                               unsigned m, unsigned n, unsigned k,
+                               const petit_solution_hints *hints,
+                               uint64_t solution_id, void *stream);
+
+/* Enumerate the kernels that can run (hints, m, n, k).  Count-then-fill: call
+ * with sols == NULL to get *n_sols, then again with a buffer of that size.
+ *   replaces fp4::GemmGetSolutions     quantization/gemm.h:132-133
+ *            (impl fp4/algo_chooser.cc:14-62)
+ * Returns 0, or -1 when hints->b_type is not an FP4 type (algo_chooser.cc:20-23).
+ * Ids use the reference's 64-bit SolutionId bit layout (gemm.h:33-66). */
+int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m,
+                             unsigned n, unsigned k, uint64_t *sols,
+                             unsigned *n_sols);
+
+/* The id the library would pick for PETIT_SOLUTION_AUTO (arch table first,
+ * heuristic second); 0 when nothing fits.
+ *   replaces fp4::ChooseDefaultFp4Fp16Solution  fp4/algo_chooser.cc:64-132 */
+uint64_t petit_gemm_default_solution(const petit_solution_hints *hints,
+                                     unsigned m, unsigned n, unsigned k);
+
+/*
+ * Offline repack of checkpoint tensors into the packed layout the GEMM reads
+ * (petit-kernel_amd/csrc/layout.h).  Same byte counts in and out.
+ *   in_chan = K, out_chan = N (argument order of the reference).
+ *
+ * petit_repack_nvfp4_weights   replaces fp4::RepackNvFp4ToPetitFp4Weights
+ *     quantization/gemm.h:135-137 (impl fp4/quantization_utils.cu:729-746)
+ *     input  u32 [N][K/8], nibble i of word k8 = element 8*k8+i
+ *     needs  N % 16 == 0, K % 128 == 0   (lib/pybind/fp4.cc:40-43)
+ *     Also used for MXFP4 weights (petit_kernel/__init__.py:27-28).
+ * petit_repack_nvfp4_scales    replaces fp4::RepackNvFp4ToPetitFp4Scales
+ *     quantization/gemm.h:139-141 (impl quantization_utils.cu:748-760)
+ *     input  e4m3 [N][K/16];  needs N % 16 == 0, K % 256 == 0 (fp4.cc:82-92)
+ * petit_repack_mxfp4_scales    replaces fp4::RepackMxFp4ToPetitFp4Scales
+ *     quantization/gemm.h:143-145 (impl quantization_utils.cu:762-773)
+ *     input  e8m0 [N][K/32];  needs N % 16 == 0, K % 256 == 0 (fp4.cc:126-135)
+ *
+ * Unlike the reference (which returns void and silently skips remainders,
+ * quantization_utils.cu:734), these return PETIT_ERROR_PROBLEM_SHAPE for a
+ * shape they cannot honour.
+ */
+int petit_repack_nvfp4_weights(unsigned *output, const unsigned *input,
+                               unsigned in_chan, unsigned out_chan, void *stream);
+int petit_repack_nvfp4_scales(unsigned *out_scales, const unsigned *scales,
+                              unsigned in_chan, unsigned out_chan, void *stream);
+int petit_repack_mxfp4_scales(unsigned *out_scales, const unsigned *scales,
+                              unsigned in_chan, unsigned out_chan, void *stream);
+
+/*
+ * Optional fp32 scratch for kernels that split K across workgroups.  The
+ * reference API has no workspace argument (SURVEY.md section 8b "Ownership");
+ * kernels that need one are only selected when a workspace of sufficient
+ * size has been registered for the current device.  Pass (NULL, 0) to
+ * unregister.  The memory stays owned by the caller.
+ */
+int petit_set_workspace(void *device_ptr, uint64_t bytes);
+/* Bytes a given solution needs for (m, n); 0 for solutions without split-K. */
+uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
+
+/* Human-readable text for a return code. */
+const char *petit_error_string(int code);
+/* Layout tag of the packed tensors ("petit-cdna4/1") and library version. */
+const char *petit_layout_tag(void);
+const char *petit_version(void);
+/* One-line description of a solution id ("stream bf16xnvfp4 mt1 nt1 wn1 wk8 d8 ..."),
+ * written into buf (at most len bytes, NUL-terminated). Returns 0 or
+ * PETIT_ERROR_KERNEL_SHAPE for an unknown id. */
+int petit_describe_solution(uint64_t solution_id, char *buf, unsigned len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETIT_AMD_H_ */

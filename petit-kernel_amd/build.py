@@ -1,0 +1,70 @@
+"""Build libpetit_amd.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python petit-kernel_amd/build.py [--force] [-j N]
+
+One object per translation unit, compiled in parallel, linked into
+petit-kernel_amd/lib/libpetit_amd.so.  No cmake, no torch: the library's only
+dependency is the HIP runtime.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+CSRC = ROOT / "csrc"
+OBJ = ROOT / "build"
+LIB = ROOT / "lib" / "libpetit_amd.so"
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc", "-DNDEBUG"]
+
+
+def sources():
+    return sorted(CSRC.glob("*.hip"))
+
+
+def deps_mtime() -> float:
+    files = list(CSRC.glob("*.h")) + list(CSRC.glob("*.cuh")) + list(CSRC.glob("*.inc"))
+    files.append(ROOT.parent / "include" / "petit_amd.h")
+    return max(f.stat().st_mtime for f in files)
+
+
+def compile_one(src: Path, force: bool, hdr_mtime: float) -> Path:
+    obj = OBJ / (src.stem + ".o")
+    if not force and obj.exists() and obj.stat().st_mtime > max(src.stat().st_mtime, hdr_mtime):
+        return obj
+    cmd = ["hipcc", *FLAGS, "-c", str(src), "-o", str(obj)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError(f"hipcc failed on {src.name}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, jobs: int | None = None) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    LIB.parent.mkdir(exist_ok=True)
+    hdr = deps_mtime()
+    srcs = sources()
+    jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: compile_one(s, force, hdr), srcs))
+    if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
+        cmd = ["hipcc", "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("-j", type=int, default=None)
+    a = ap.parse_args()
+    print(build(a.force, a.j))

@@ -1,0 +1,310 @@
+// api.hip -- host side of libpetit_amd.so: the C ABI of include/petit_amd.h,
+// solution lookup and the default-solution choice.
+//
+// Replaces (reference paths under lib/gemm/rocm/quantization/):
+//   fp4/gemm_fp4_fp16_grid.cc:11-95   Dispatcher, GemmFp4Fp16GridImpl, GemmMxFp4Fp16Grid
+//   fp4/algo_chooser.cc:14-132        GemmGetSolutions, ChooseDefaultFp4Fp16Solution
+//   fp4/solution_map.cc, fp4/gen_solution_list.cc   (build-time kernel list)
+// The reference scans a 234-entry map on every call with solution_id = -1
+// (algo_chooser.cc:116-126); here the choice is a handful of integer compares
+// against the arch table (hal.h) and the table lookup is a linear scan over
+// < 20 entries of one (dtype, format) family.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/petit_amd.h"
+#include "gemm_stream.cuh"
+#include "hal.h"
+#include "layout.h"
+#include "petit_internal.h"
+#include "solution.h"
+
+namespace petit_amd {
+namespace {
+
+struct Family {
+    const SolutionEntry *entries;
+    int count;
+    unsigned elem_b, mfma;
+};
+
+bool family_for(int a_type, int b_type, Family *out) {
+    const bool mx = (b_type == kDataTypeMxFp4e2m1);
+    if (b_type != kDataTypeFp4e2m1 && !mx)
+        return false;
+    if (a_type == kDataTypeBf16 && !mx) {
+        out->entries = solutions_nv_bf16(&out->count);
+        out->elem_b = kElemBNvFp4, out->mfma = kMfmaBf16;
+        return true;
+    }
+    if (a_type == kDataTypeFp16 && !mx) {
+        out->entries = solutions_nv_f16(&out->count);
+        out->elem_b = kElemBNvFp4, out->mfma = kMfmaFp16;
+        return true;
+    }
+    if (a_type == kDataTypeBf16 && mx) {
+        out->entries = solutions_mx_bf16(&out->count);
+        out->elem_b = kElemBMxFp4, out->mfma = kMfmaBf16;
+        return true;
+    }
+    return false;
+}
+
+bool shape_ok(unsigned n, unsigned k) { return n % kTileN == 0 && k % 256 == 0; }
+
+// Can this entry run (m, n, k)?  Only KS has to match the layout K implies.
+bool entry_fits(const SolutionEntry &e, unsigned k) { return e.shape.ks == span_tiles_for_k(k); }
+
+// Per-device registered split-K workspace.
+constexpr int kMaxDevices = 64;
+struct Workspace {
+    std::atomic<void *> ptr{nullptr};
+    std::atomic<uint64_t> bytes{0};
+};
+Workspace g_workspace[kMaxDevices];
+
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+        return 0;
+    return dev;
+}
+
+uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
+    return splitk > 1 ? (uint64_t)splitk * m * n * sizeof(float) : 0;
+}
+
+// Default choice when the arch table has no entry: pick the shape whose
+// workgroup count best fills the chip without starving each wave of work.
+// (The reference's heuristic ignores the CU count altogether and leaves half of
+// a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
+const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k) {
+    const ArchInfo &arch = arch_info(current_device());
+    const unsigned ntiles = n / kTileN;
+    const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    const unsigned want_mt = m <= 16 ? 1 : m <= 32 ? 2 : 4;
+    const SolutionEntry *best = nullptr;
+    double best_score = -1.0;
+    for (int i = 0; i < fam.count; ++i) {
+        const SolutionEntry &e = fam.entries[i];
+        if (!entry_fits(e, k))
+            continue;
+        const StreamShape &s = e.shape;
+        if (s.mt != (int)want_mt && !(m > 64 && s.mt == 4))
+            continue;
+        const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
+        const unsigned waves = wgs * s.wn * s.wk;
+        // waves that actually get a span
+        const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
+        const double busy = (double)wgs * s.wn * busy_wk;
+        // fill: up to ~8 waves per SIMD keeps enough bytes in flight
+        const double slots = (double)arch.num_cus * 4 * 4;
+        double score = busy < slots ? busy / slots : 1.0;
+        // activation re-reads: prefer more n-tiles per wave as M grows
+        const double a_over_w = (double)(m < 16 ? m : 16) / (4.0 * s.nt);
+        score /= (1.0 + 0.5 * a_over_w);
+        // mild preference for fewer idle waves and deeper rings
+        score *= 1.0 - 0.1 * (1.0 - busy / (double)waves);
+        score *= 1.0 + 0.01 * s.d;
+        if (score > best_score)
+            best_score = score, best = &e;
+    }
+    return best;
+}
+
+const SolutionEntry *find_entry(const Family &fam, uint64_t id) {
+    const uint64_t key = solution_without_splitk(id);
+    for (int i = 0; i < fam.count; ++i)
+        if (make_solution_id(fam.entries[i].shape, fam.elem_b, fam.mfma, 1) == key)
+            return &fam.entries[i];
+    return nullptr;
+}
+
+int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+              const float *global_scale, unsigned m, unsigned n, unsigned k,
+              const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
+    if (m == 0 || n == 0 || k == 0)
+        return kOk; // gemm_fp4_fp16_grid.cc:42-44
+    if (!hints || !c || !a || !b || !scales || !global_scale)
+        return kErrBadArgument;
+    if (hints->c_type != hints->a_type)
+        return kErrKernelShape;
+    Family fam;
+    if (!family_for(hints->a_type, b_type, &fam))
+        return kErrKernelShape;
+    if (!shape_ok(n, k))
+        return kErrProblemShape;
+    // 32-bit buffer offsets inside one n-tile row / activation block
+    if ((uint64_t)k * 16 * 4 * 2 >= (1ull << 31) || (uint64_t)k * 64 * 4 >= (1ull << 31))
+        return kErrProblemShape;
+
+    const SolutionEntry *entry = nullptr;
+    unsigned splitk = 1;
+    if (solution_id == PETIT_SOLUTION_AUTO) {
+        uint64_t tuned = tuned_solution(current_device(), hints->a_type, b_type, m, n, k);
+        if (tuned) {
+            entry = find_entry(fam, tuned);
+            splitk = solution_splitk(tuned);
+        }
+        if (entry && !entry_fits(*entry, k))
+            entry = nullptr;
+        if (!entry) {
+            entry = heuristic(fam, m, n, k);
+            splitk = 1;
+        }
+        if (!entry)
+            return kErrKernelShape;
+    } else {
+        entry = find_entry(fam, solution_id);
+        if (!entry)
+            return kErrKernelShape;
+        if (!entry_fits(*entry, k))
+            return kErrProblemShape;
+        splitk = solution_splitk(solution_id);
+        if (splitk == 0)
+            return kErrKernelShape;
+    }
+
+    GemmArgs args{};
+    args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
+    args.m = m, args.n = n, args.k = k;
+    if (splitk > 1) {
+        Workspace &ws = g_workspace[current_device()];
+        const uint64_t need = splitk_bytes(splitk, m, n);
+        if (ws.ptr.load() == nullptr || ws.bytes.load() < need) {
+            if (solution_id != PETIT_SOLUTION_AUTO)
+                return kErrKernelShape; // explicit id that needs a workspace nobody registered
+            splitk = 1;                 // tuned pick without workspace: fall back in-family
+        } else {
+            args.workspace = (float *)ws.ptr.load();
+        }
+    }
+    return entry->launch(args, splitk, (hipStream_t)stream);
+}
+
+} // namespace
+} // namespace petit_amd
+
+using namespace petit_amd;
+
+extern "C" {
+
+int petit_gemm_fp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+                             const float *global_scale, unsigned m, unsigned n, unsigned k,
+                             const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
+    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, stream);
+}
+
+int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+                               const float *global_scale, unsigned m, unsigned n, unsigned k,
+                               const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
+    // the reference forces element_b = MxFp4 into the id (gemm_fp4_fp16_grid.cc:79-95)
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, stream);
+}
+
+int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
+                             uint64_t *sols, unsigned *n_sols) {
+    (void)m;
+    if (!hints || !n_sols)
+        return -1;
+    if (hints->b_type != kDataTypeFp4e2m1 && hints->b_type != kDataTypeMxFp4e2m1)
+        return -1; // algo_chooser.cc:20-23
+    Family fam;
+    unsigned count = 0;
+    const unsigned cap = sols ? *n_sols : 0;
+    if (hints->c_type == hints->a_type && family_for(hints->a_type, hints->b_type, &fam) && shape_ok(n, k)) {
+        for (int i = 0; i < fam.count; ++i) {
+            if (!entry_fits(fam.entries[i], k))
+                continue;
+            if (sols && count < cap)
+                sols[count] = make_solution_id(fam.entries[i].shape, fam.elem_b, fam.mfma, 1);
+            ++count;
+        }
+    }
+    *n_sols = count;
+    return 0;
+}
+
+uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k) {
+    Family fam;
+    if (!hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) ||
+        !shape_ok(n, k) || m == 0)
+        return 0;
+    uint64_t tuned = tuned_solution(current_device(), hints->a_type, hints->b_type, m, n, k);
+    if (tuned) {
+        const SolutionEntry *e = find_entry(fam, tuned);
+        if (e && entry_fits(*e, k))
+            return tuned;
+    }
+    const SolutionEntry *e = heuristic(fam, m, n, k);
+    return e ? make_solution_id(e->shape, fam.elem_b, fam.mfma, 1) : 0;
+}
+
+int petit_repack_nvfp4_weights(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan,
+                               void *stream) {
+    if ((!output || !input) && in_chan && out_chan)
+        return kErrBadArgument;
+    return repack_weights(output, input, in_chan, out_chan, (hipStream_t)stream);
+}
+int petit_repack_nvfp4_scales(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan,
+                              void *stream) {
+    if ((!out_scales || !scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return repack_nvscales(out_scales, scales, in_chan, out_chan, (hipStream_t)stream);
+}
+int petit_repack_mxfp4_scales(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan,
+                              void *stream) {
+    if ((!out_scales || !scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return repack_mxscales(out_scales, scales, in_chan, out_chan, (hipStream_t)stream);
+}
+
+int petit_set_workspace(void *device_ptr, uint64_t bytes) {
+    Workspace &ws = g_workspace[current_device()];
+    ws.bytes.store(0);
+    ws.ptr.store(device_ptr);
+    ws.bytes.store(device_ptr ? bytes : 0);
+    return kOk;
+}
+
+uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n) {
+    return splitk_bytes(solution_splitk(solution_id), m, n);
+}
+
+const char *petit_error_string(int code) {
+    switch (code) {
+    case kOk: return "ok";
+    case kErrProblemShape: return "incompatible problem shape";
+    case kErrKernelShape: return "no kernel implementation for this solution id / dtype combination";
+    case kErrLaunch: return "kernel launch failed";
+    case kErrBadArgument: return "bad argument";
+    default: return "unknown error";
+    }
+}
+
+const char *petit_layout_tag(void) { return "petit-cdna4/1"; }
+const char *petit_version(void) { return "petit-kernel_amd 0.1.0 (gfx950)"; }
+
+int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
+    if (!buf || len == 0)
+        return kErrBadArgument;
+    const unsigned elem_b = (unsigned)(id >> 28) & 0xf, mfma = (unsigned)(id >> 32) & 0xf;
+    const int a_type = mfma == kMfmaBf16 ? kDataTypeBf16 : kDataTypeFp16;
+    const int b_type = elem_b == kElemBMxFp4 ? kDataTypeMxFp4e2m1 : kDataTypeFp4e2m1;
+    Family fam;
+    const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_entry(fam, id) : nullptr;
+    if (!e) {
+        snprintf(buf, len, "unknown solution 0x%llx", (unsigned long long)id);
+        return kErrKernelShape;
+    }
+    const StreamShape &s = e->shape;
+    snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d splitk%u  (wg tile %dx%d, %d threads)",
+             a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
+             s.mt, s.nt, s.wn, s.wk, s.d, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * s.wk);
+    return kOk;
+}
+
+} // extern "C"

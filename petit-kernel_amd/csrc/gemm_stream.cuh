@@ -1,0 +1,426 @@
+// gemm_stream.cuh -- the weight-streaming FP4 GEMM for small M (decode regime).
+//
+// Replaces GemmFp4Fp16KernelGrid and everything under it
+// (fp4/gemm_fp4_fp16_grid.cuh:441-498, fp4/warp_schedule_fp16.cuh:73-193,
+// quantization/dequant.cuh, quantization/memory_ops.cuh, qgemm.cuh,
+// gpu/quantization/reduce.cuh) for M small enough that the op is a scan of W.
+//
+// Design (gfx950):
+//  * W is used exactly once, so it never touches LDS: every wave streams whole
+//    1 KiB tiles (layout.h) straight into VGPRs with non-temporal
+//    buffer_load_dwordx4, a ring of D tiles per n-tile deep, and there is no
+//    barrier anywhere in the main loop (the reference round-trips every W byte
+//    global -> VGPR -> LDS -> VGPR with 2-4 barriers per K step,
+//    gemm_fp4_fp16_grid.cuh:353-394).
+//  * Unpack is the hardware E2M1 convert (v_cvt_scalef32_pk_*_fp4): 4 VALU per
+//    8 weights for MX (block scale folded into the convert), +4 v_pk_mul for the
+//    non-power-of-two NV group scale.  The reference needs bfrev/and/cvt_bf8/
+//    perm sequences and a nibble re-encode (dequant.cuh:326-363).
+//  * The contraction is v_mfma_f32_16x16x32_{bf16,f16} computed as
+//    C^T[n][m] = W[n][k] . A[m][k]: W is the 16-row operand, the activations are
+//    the 16-column operand, so a lane ends with 4 consecutive n of one m and the
+//    epilogue store is one 8-byte write.
+//  * K is split across the WK waves of a workgroup (and optionally across
+//    gridDim.z workgroups); partial sums meet once, in LDS, after the loop.
+//  * A rows beyond M and n-tiles beyond N/16 are masked by buffer-descriptor
+//    bounds (out-of-range loads return 0), so M and N/16 need not divide the
+//    tile.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "layout.h"
+#include "petit_internal.h"
+
+namespace petit_amd {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+enum : int { kFmtNv = 0, kFmtMx = 1 };
+
+// gfx940-family cache-policy bits of the buffer intrinsics' aux operand.
+enum : int { kAuxDefault = 0, kAuxNt = 2 };
+
+struct Bf16 {
+    using frag = bf16x8;
+    static constexpr int kType = kDataTypeBf16;
+};
+struct Fp16 {
+    using frag = f16x8;
+    static constexpr int kType = kDataTypeFp16;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    // raw buffer, no swizzle, bounds-checked: 0x00020000 = DATA_FORMAT_32
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff,
+                                            int aux) {
+    // aux must be a literal for the builtin
+    if (aux == kAuxNt)
+        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxNt));
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxDefault));
+}
+
+// --- unpack: one 32-bit word = 8 consecutive-k E2M1 values -> one MFMA operand --
+
+template <int SEL> __device__ __forceinline__ f32x2 cvt_fp4_f32(unsigned w, float scale) {
+    return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, scale, SEL);
+}
+template <int SEL> __device__ __forceinline__ bf16x2 cvt_fp4_bf16(unsigned w, float scale) {
+    return __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, SEL);
+}
+template <int SEL> __device__ __forceinline__ f16x2 cvt_fp4_f16(unsigned w, float scale) {
+    return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, scale, SEL);
+}
+
+// NVFP4 -> bf16: exact (fp4 x e4m3 needs <= 5 significant bits).
+__device__ __forceinline__ bf16x8 unpack_nv(Bf16, unsigned w, float s) {
+    f32x2 p0 = cvt_fp4_f32<0>(w, 1.0f) * s;
+    f32x2 p1 = cvt_fp4_f32<1>(w, 1.0f) * s;
+    f32x2 p2 = cvt_fp4_f32<2>(w, 1.0f) * s;
+    f32x2 p3 = cvt_fp4_f32<3>(w, 1.0f) * s;
+    bf16x2 q0 = __builtin_convertvector(p0, bf16x2);
+    bf16x2 q1 = __builtin_convertvector(p1, bf16x2);
+    bf16x2 q2 = __builtin_convertvector(p2, bf16x2);
+    bf16x2 q3 = __builtin_convertvector(p3, bf16x2);
+    return bf16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+}
+// NVFP4 -> fp16: exact (|fp4 * s| <= 2688, >= 2^-10).
+__device__ __forceinline__ f16x8 unpack_nv(Fp16, unsigned w, float s) {
+    const f16x2 s2 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s, s));
+    f16x2 q0 = cvt_fp4_f16<0>(w, 1.0f) * s2;
+    f16x2 q1 = cvt_fp4_f16<1>(w, 1.0f) * s2;
+    f16x2 q2 = cvt_fp4_f16<2>(w, 1.0f) * s2;
+    f16x2 q3 = cvt_fp4_f16<3>(w, 1.0f) * s2;
+    return f16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+}
+// MXFP4 -> bf16: the e8m0 block scale (a power of two) rides in the convert.
+__device__ __forceinline__ bf16x8 unpack_mx(Bf16, unsigned w, float s) {
+    bf16x2 q0 = cvt_fp4_bf16<0>(w, s);
+    bf16x2 q1 = cvt_fp4_bf16<1>(w, s);
+    bf16x2 q2 = cvt_fp4_bf16<2>(w, s);
+    bf16x2 q3 = cvt_fp4_bf16<3>(w, s);
+    return bf16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+}
+
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// e4m3 byte SEL of a packed dword -> f32 (OCP e4m3 on gfx950).
+template <int SEL> __device__ __forceinline__ float e4m3_byte(unsigned packed) {
+    return __builtin_amdgcn_cvt_f32_fp8((int)packed, SEL);
+}
+// e8m0 byte SEL of a packed dword -> f32 2^(e-127)  (dequant.cuh:198-203).
+template <int SEL> __device__ __forceinline__ float e8m0_byte(unsigned packed) {
+    return __builtin_bit_cast(float, ((packed >> (8 * SEL)) & 0xffu) << 23);
+}
+
+__device__ __forceinline__ unsigned pack2(Bf16, float lo, float hi) {
+    bf16x2 q = __builtin_convertvector(f32x2{lo, hi}, bf16x2); // RNE, qgemm.cuh:161-176
+    return __builtin_bit_cast(unsigned, q);
+}
+__device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi) {
+    f16x2 q = __builtin_convertvector(f32x2{lo, hi}, f16x2); // RNE
+    return __builtin_bit_cast(unsigned, q);
+}
+
+// Scale record of one span for one n-tile: KS*2 bytes (NV) / KS bytes (MX).
+template <int FMT, int KS> struct ScaleRec {
+    static constexpr int kBytes = (FMT == kFmtNv ? 2 : 1) * KS;
+    static constexpr int kDwords = (kBytes + 3) / 4;
+    unsigned d[kDwords];
+};
+
+template <int FMT, int KS>
+__device__ __forceinline__ ScaleRec<FMT, KS> load_scale_rec(__amdgpu_buffer_rsrc_t r, unsigned voff,
+                                                            unsigned soff) {
+    ScaleRec<FMT, KS> out;
+    constexpr int B = ScaleRec<FMT, KS>::kBytes;
+    if constexpr (B == 16) {
+        u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxNt));
+        out.d[0] = v[0], out.d[1] = v[1], out.d[2] = v[2], out.d[3] = v[3];
+    } else if constexpr (B == 8) {
+        u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxNt));
+        out.d[0] = v[0], out.d[1] = v[1];
+    } else if constexpr (B == 4) {
+        out.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxNt);
+    } else {
+        static_assert(B == 2, "span record is 2, 4, 8 or 16 bytes");
+        out.d[0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, kAuxNt);
+    }
+    return out;
+}
+
+// The two group scales (NV) or the block scale (MX) of tile T of the span.
+template <int FMT, int KS, int T>
+__device__ __forceinline__ void tile_scales(const ScaleRec<FMT, KS> &rec, float &s_lo, float &s_hi) {
+    if constexpr (FMT == kFmtNv) {
+        constexpr int byte = 2 * T;
+        s_lo = e4m3_byte<byte % 4>(rec.d[byte / 4]);
+        s_hi = e4m3_byte<(byte + 1) % 4>(rec.d[(byte + 1) / 4]);
+    } else {
+        s_lo = s_hi = e8m0_byte<T % 4>(rec.d[T / 4]);
+    }
+}
+
+// Compile-time loop with a constant index (scale-record bytes, ring slots and
+// convert byte-selects must all be literals).
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Compile-time configuration of one kernel instance.
+//   AT    Bf16 / Fp16 activations (and output)
+//   FMT   kFmtNv / kFmtMx
+//   KS    tiles per span (scale-record granularity; layout.h)
+//   MT    m-tiles (of 16) per workgroup
+//   NT    n-tiles (of 16) per wave
+//   WN,WK waves along N / K in the workgroup
+//   D     ring depth (tiles in flight per n-tile), D divides KS
+template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_> struct StreamCfg {
+    using AT = AT_;
+    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_;
+    static constexpr int kThreads = 64 * WN * WK;
+    static_assert(KS % D == 0, "ring depth must divide the span");
+    static_assert(kThreads <= 1024, "workgroup too large");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmArgs p) {
+    using AT = typename Cfg::AT;
+    using Frag = typename AT::frag;
+    constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT;
+    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D;
+    constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
+    // A voffset this large is out of range for every descriptor built below
+    // whatever the generation's rule for soffset is (masked loads use soffset 0).
+    constexpr unsigned kOob = 0x80000000u;
+
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned wn = wave % WN, wk = wave / WN;
+    const unsigned r = lane & 15u, g = lane >> 4;
+
+    const unsigned ktiles = p.k / kTileK;
+    const unsigned nspans = ktiles / KS;
+    const unsigned ntiles = p.n / kTileN;
+    const unsigned nt0 = (blockIdx.x * WN + wn) * NT;
+    const unsigned m0 = blockIdx.y * (16 * MT);
+
+    // K range of this wave: contiguous spans.  gridDim.z splits K across
+    // workgroups first, WK across the waves of a workgroup second.
+    const unsigned kparts = gridDim.z * WK;
+    const unsigned part = blockIdx.z * WK + wk;
+    const unsigned chunk = (nspans + kparts - 1) / kparts;
+    const unsigned sp_begin = min(part * chunk, nspans);
+    const unsigned sp_end = min(sp_begin + chunk, nspans);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nt0 < ntiles && sp_begin < sp_end) {
+        const unsigned valid_nt = min((unsigned)NT, ntiles - nt0);
+        const unsigned w_row_bytes = ktiles * kTileBytes;             // one n-tile of W
+        const unsigned s_row_bytes = (FMT == kFmtNv) ? p.k : p.k / 2; // one n-tile of scales
+        const unsigned rows = min(p.m - m0, (unsigned)(16 * MT));
+
+        const __amdgpu_buffer_rsrc_t w_rsrc =
+            make_rsrc((const char *)p.w + (size_t)nt0 * w_row_bytes, valid_nt * w_row_bytes);
+        const __amdgpu_buffer_rsrc_t s_rsrc =
+            make_rsrc((const char *)p.s + (size_t)nt0 * s_row_bytes, valid_nt * s_row_bytes);
+        const __amdgpu_buffer_rsrc_t a_rsrc =
+            make_rsrc((const char *)p.a + (size_t)m0 * p.k * 2, rows * p.k * 2);
+
+        // Everything that decides validity lives in the VGPR offset (bounds
+        // checked on every generation); the SGPR offset only walks along K.
+        unsigned w_voff[NT], s_voff[NT], a_voff[MT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + nt * w_row_bytes : kOob;
+            s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + nt * s_row_bytes : kOob;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            a_voff[mt] = ((mt * 16 + r) * p.k + g * kLaneK) * 2; // rows >= M fall out of range
+
+        const unsigned kt_begin = sp_begin * KS, kt_end = sp_end * KS;
+
+        // --- prologue: fill the W ring, first scale records, first A fragments
+        u32x4 wring[D][NT];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool ok = kt_begin + i < kt_end;
+                wring[i][nt] = buf_load16(w_rsrc, ok ? w_voff[nt] : kOob,
+                                          ok ? (kt_begin + i) * kTileBytes : 0u, kAuxNt);
+            }
+        ScaleRec<FMT, KS> srec[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], sp_begin * 64 * kRecBytes);
+
+        u32x4 afrag[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
+
+        for (unsigned sp = sp_begin; sp < sp_end; ++sp) {
+            const unsigned kt0 = sp * KS;
+            // next span's scale records (masked past the end of this wave's range)
+            ScaleRec<FMT, KS> srec_next[NT];
+            {
+                const bool ok = sp + 1 < sp_end;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    srec_next[nt] = load_scale_rec<FMT, KS>(s_rsrc, ok ? s_voff[nt] : kOob,
+                                                            ok ? (sp + 1) * 64 * kRecBytes : 0u);
+            }
+
+            static_for<0, KS>([&](auto t_c) {
+                constexpr int T = decltype(t_c)::value;
+                constexpr int SLOT = T % D;
+                const unsigned kt = kt0 + T;
+                // take this step's tiles out of the ring, refill the slot D steps ahead
+                u32x4 wcur[NT];
+                {
+                    const bool ok = kt + D < kt_end;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        wcur[nt] = wring[SLOT][nt];
+                        wring[SLOT][nt] = buf_load16(w_rsrc, ok ? w_voff[nt] : kOob,
+                                                     ok ? (kt + D) * kTileBytes : 0u, kAuxNt);
+                    }
+                }
+                // next step's activation fragments
+                u32x4 anext[MT][4];
+                {
+                    const bool ok = kt + 1 < kt_end;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const unsigned vo = ok ? a_voff[mt] : kOob;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            anext[mt][j] = buf_load16(a_rsrc, vo + j * 16, ok ? (kt + 1) * 256 : 0u, kAuxDefault);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float s_lo, s_hi;
+                    tile_scales<FMT, KS, T>(srec[nt], s_lo, s_hi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Frag wf;
+                        if constexpr (FMT == kFmtNv)
+                            wf = unpack_nv(AT{}, wcur[nt][j], j < 2 ? s_lo : s_hi);
+                        else
+                            wf = unpack_mx(AT{}, wcur[nt][j], s_lo);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nt] = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), acc[mt][nt]);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        afrag[mt][j] = anext[mt][j];
+            });
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                srec[nt] = srec_next[nt];
+        }
+    }
+
+    // --- cross-wave K reduction through LDS, then the epilogue -----------------
+    // (gpu/quantization/reduce.cuh:7-58 + qgemm.cuh:95-192 in the reference)
+    const float gs = *p.gs;
+    // one float4 = rows n..n+3 of column m:  x global scale, one RNE rounding,
+    // one 8-byte store (or the fp32 slab of this K part when gridDim.z > 1)
+    auto emit = [&](f32x4 v, unsigned iwn, unsigned imt, unsigned inn, unsigned il) {
+        const unsigned m = m0 + imt * 16 + (il & 15u);
+        const unsigned ntile = (blockIdx.x * WN + iwn) * NT + inn;
+        const unsigned n = ntile * 16 + (il >> 4) * 4;
+        if (m >= p.m || ntile >= ntiles)
+            return;
+        if (gridDim.z == 1) {
+            uint2 o;
+            o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
+            o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
+            *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = o;
+        } else {
+            float *slab = p.workspace + ((size_t)blockIdx.z * p.m + m) * p.n + n;
+            *reinterpret_cast<f32x4 *>(slab) = v;
+        }
+    };
+
+    if constexpr (WK == 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                emit(acc[mt][nt], wn, mt, nt, lane);
+    } else {
+        constexpr int kItems = WN * MT * NT * 64; // float4 outputs of the workgroup
+        __shared__ f32x4 red[WK * kItems];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                red[wk * kItems + ((wn * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt];
+        __syncthreads();
+        for (unsigned item = threadIdx.x; item < (unsigned)kItems; item += Cfg::kThreads) {
+            f32x4 v = red[item];
+#pragma unroll
+            for (int q = 1; q < WK; ++q)
+                v += red[q * kItems + item];
+            const unsigned tile = item >> 6;
+            emit(v, tile / (MT * NT), (tile / NT) % MT, tile % NT, item & 63u);
+        }
+    }
+}
+
+// Second pass of the cross-workgroup split-K: sum the fp32 slabs in a fixed
+// order (deterministic), apply the global scale, round once.
+template <class AT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(void *c, const float *ws, const float *gs_ptr,
+                                                            unsigned m, unsigned n, unsigned parts) {
+    const size_t total4 = (size_t)m * n / 4;
+    const float gs = *gs_ptr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<const f32x4 *>(ws)[i];
+        for (unsigned q = 1; q < parts; ++q)
+            v += reinterpret_cast<const f32x4 *>(ws + (size_t)q * m * n)[i];
+        uint2 o;
+        o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
+        o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
+        reinterpret_cast<uint2 *>(c)[i] = o;
+    }
+}
+
+} // namespace petit_amd

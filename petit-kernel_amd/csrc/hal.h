@@ -1,0 +1,49 @@
+// hal.h -- "hardware abstraction" of this build: the per-device arch record and
+// the tuned-solution table consulted for solution_id = -1.
+//
+// The reference's lib/hal is a hipMalloc/hipMemcpy wrapper for its gtests
+// (lib/hal/device.h:8-34) and has no arch knowledge at all: its only arch
+// switches are two #ifs and a `major*10+minor <= 90` test
+// (lib/pybind/fp4.cc:24-34), and its default-solution heuristic is blind to
+// the CU count (fp4/algo_chooser.cc:64-132).  BASELINE.json asks for arch
+// tables, so the name is reused for what is new here:
+//   * ArchInfo   -- CU count, LDS size, clocks, queried once per device;
+//   * the tuned table -- (a_type, b_type, N, K, M range) -> solution id, the
+//     persisted result of tools/tune.py sweeps on a real MI355X
+//     (tuned_gfx950.inc), overridable at run time through the text file named
+//     by $PETIT_AMD_TUNE_FILE (same columns, one entry per line).
+#pragma once
+
+#include <stdint.h>
+
+namespace petit_amd {
+
+struct ArchInfo {
+    char name[32];         // "gfx950"
+    int num_cus;           // 256 on MI355X
+    int lds_bytes_per_cu;  // 163840
+    int max_waves_per_cu;  // 32
+    int clock_khz;         // peak engine clock
+    int mem_clock_khz;
+    int mem_bus_bits;
+    double hbm_peak_gbs;   // spec: 8000 GB/s on MI355X
+    double bf16_peak_tflops; // dense: 2500
+    double fp4_peak_tflops;  // dense: 10000
+    bool native_fp4;       // v_mfma_scale_f32_*_f8f6f4 + v_cvt_scalef32_*_fp4
+};
+
+// Cached after the first call per device; never fails (falls back to the
+// MI355X datasheet record when the runtime query does).
+const ArchInfo &arch_info(int device);
+
+struct TunedEntry {
+    int a_type, b_type; // DataType values (petit_internal.h)
+    unsigned n, k;
+    unsigned m_lo, m_hi; // inclusive range of M this entry covers
+    uint64_t solution;   // full id incl. split-K nibble
+};
+
+// 0 when the table has no entry for this problem.
+uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k);
+
+} // namespace petit_amd

@@ -1,0 +1,50 @@
+// petit_internal.h -- declarations shared by the translation units of
+// libpetit_amd.so.  Not installed; the public surface is include/petit_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace petit_amd {
+
+// Error codes.  0/1/2 are the reference's (quantization/gemm.h:107-108);
+// the rest are additions of this library (launch failures are polled here,
+// the reference never does -- SURVEY.md section 5).
+enum : int {
+    kOk = 0,
+    kErrProblemShape = 1, // kErrorProblemShape
+    kErrKernelShape = 2,  // kErrorKernelShape
+    kErrLaunch = 3,       // hipGetLastError() != hipSuccess after a launch
+    kErrBadArgument = 4,  // null pointer / unknown dtype
+};
+
+// Arithmetic / element types, numbered as the reference's C++ DataType
+// (quantization/types.h:4-13).
+enum DataType : int {
+    kDataTypeInt4 = 0,
+    kDataTypeFp8e4m3 = 1,
+    kDataTypeFp8e8m0 = 2,
+    kDataTypeFp4e2m1 = 3,
+    kDataTypeFp16 = 4,
+    kDataTypeBf16 = 5,
+    kDataTypeFp8e5m2Fnuz = 6,
+    kDataTypeMxFp4e2m1 = 7,
+};
+
+struct GemmArgs {
+    void *c;            // [m][n] 16-bit, row-major
+    const void *a;      // [m][k] 16-bit, row-major
+    const void *w;      // packed weights (layout.h)
+    const void *s;      // packed scales  (layout.h)
+    const float *gs;    // device pointer, one float
+    float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
+    unsigned *counters; // split-K arrival tickets (may be null when splitk == 1)
+    unsigned m, n, k;
+};
+
+// repack.hip
+int repack_weights(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
+int repack_nvscales(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
+int repack_mxscales(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
+
+} // namespace petit_amd

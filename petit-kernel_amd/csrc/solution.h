@@ -1,0 +1,63 @@
+// solution.h -- 64-bit solution ids and the kernel table of libpetit_amd.so.
+//
+// Ids keep the bit layout of the reference's SolutionId bitfield
+// (lib/gemm/rocm/quantization/gemm.h:33-66) so that tools which print or
+// persist ids as hex keep working; the 12 bits the reference leaves as padding
+// (:45) carry the knobs that only exist in the gfx950 kernels.
+//
+//   bits  0- 7  tile_m            m-tiles (of 16) per workgroup        = MT
+//   bits  8-15  tile_n            n-tiles (of 16) per workgroup        = WN*NT
+//   bits 16-23  tile_k            k per span in units of 64            = 2*KS
+//   bits 24-27  features          Grid (1) | HighPrecision (2)  -- always 3 here:
+//                                 every gfx950 kernel dequantises exactly
+//   bits 28-31  element_b         1 NVFP4, 2 MXFP4          (MatmulElementB)
+//   bits 32-35  mfma_type         0 fp16, 1 bf16            (MatmulMfmaType)
+//   bits 36-39  warp_partition_m  1
+//   bits 40-43  warp_partition_n  WN
+//   bits 44-47  warp_partition_k  WK
+//   bits 48-51  warp_partition    0 (NK)
+//   bits 52-55  [was padding]     NT  n-tiles per wave
+//   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
+//   bits 60-63  [was padding]     split-K across workgroups (gridDim.z), >= 1
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "petit_internal.h"
+
+namespace petit_amd {
+
+enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
+enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u };
+enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u };
+
+struct StreamShape {
+    int ks, mt, nt, wn, wk, d;
+};
+
+constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {
+    return (uint64_t)(s.mt & 0xff) | ((uint64_t)((s.wn * s.nt) & 0xff) << 8) |
+           ((uint64_t)((2 * s.ks) & 0xff) << 16) | ((uint64_t)(kFeatGrid | kFeatHighPrecision) << 24) |
+           ((uint64_t)(elem_b & 0xf) << 28) | ((uint64_t)(mfma & 0xf) << 32) | ((uint64_t)1 << 36) |
+           ((uint64_t)(s.wn & 0xf) << 40) | ((uint64_t)(s.wk & 0xf) << 44) | ((uint64_t)(s.nt & 0xf) << 52) |
+           ((uint64_t)(s.d & 0xf) << 56) | ((uint64_t)(splitk & 0xf) << 60);
+}
+constexpr unsigned solution_splitk(uint64_t id) { return (unsigned)(id >> 60) & 0xf; }
+constexpr uint64_t solution_without_splitk(uint64_t id) { return (id & ~((uint64_t)0xf << 60)) | ((uint64_t)1 << 60); }
+
+using LaunchFn = int (*)(const GemmArgs &, unsigned splitk, hipStream_t);
+
+struct SolutionEntry {
+    StreamShape shape;
+    int a_type; // kDataTypeBf16 / kDataTypeFp16
+    int fmt;    // kFmtNv / kFmtMx (gemm_stream.cuh)
+    LaunchFn launch;
+};
+
+// one table per (activation type, weight format) translation unit
+const SolutionEntry *solutions_nv_bf16(int *count);
+const SolutionEntry *solutions_nv_f16(int *count);
+const SolutionEntry *solutions_mx_bf16(int *count);
+
+} // namespace petit_amd

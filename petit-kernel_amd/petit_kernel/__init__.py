@@ -1,0 +1,71 @@
+"""petit_kernel -- drop-in Python surface of the MI355X (gfx950) build.
+
+Same names, signatures and tensor contracts as the reference package
+(petit_kernel/__init__.py:8-79 of causalflow-ai/petit-kernel v0.0.3):
+SGLang / vLLM call sites (`repack_nvfp4`, `process_nvfp4_scales`,
+`mul_nvfp4_a16(..., solution_id=-1)`) work unchanged.  The packed tensors
+returned by `repack_*` / `process_*_scales` keep the reference's shapes and
+dtypes but use the gfx950 layout (petit-kernel_amd/csrc/layout.h); they are
+opaque and only meaningful to `mul_*_a16` of this build.
+"""
+import enum
+
+import torch
+
+from . import ops
+from .ops import PetitSolutionHints
+
+
+class DataType(enum.Enum):
+    # numbering of the reference's Python enum (petit_kernel/__init__.py:8-15)
+    int4 = 0
+    float8_e4m3fn = 1
+    float4_e2m1 = 2
+    float16 = 3
+    bfloat16 = 4
+    float8_e5m2fn = 5
+    mxfloat4_e2m1 = 6
+
+
+def repack_nvfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    return ops.repack_nvfp4(qw, size_n, size_k)
+
+
+def process_nvfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    return ops.process_nvfp4_scales(scales, size_n, size_k)
+
+
+def repack_mxfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    # weight packing is format-independent, as in the reference (:27-28)
+    return ops.repack_nvfp4(qw, size_n, size_k)
+
+
+def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    return ops.process_mxfp4_scales(scales, size_n, size_k)
+
+
+def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
+                  size_m: int, size_n: int, size_k: int, solution_id: int = -1) -> torch.Tensor:
+    return ops.mul_nvfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id)
+
+
+def mul_mxfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
+                  size_m: int, size_n: int, size_k: int, solution_id: int = -1) -> torch.Tensor:
+    return ops.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id)
+
+
+def get_fp4_solutions(size_m: int, size_n: int, size_k: int, a_type, c_type) -> list:
+    return ops.get_fp4_solutions(size_m, size_n, size_k, a_type, c_type)
+
+
+__all__ = [
+    "repack_nvfp4",
+    "repack_mxfp4",
+    "process_nvfp4_scales",
+    "process_mxfp4_scales",
+    "mul_nvfp4_a16",
+    "mul_mxfp4_a16",
+    "get_fp4_solutions",
+    "DataType",
+    "PetitSolutionHints",
+]

@@ -1,0 +1,81 @@
+"""ctypes loader for libpetit_amd.so (the C ABI of include/petit_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing this
+module raises at import time, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parent.parent  # petit-kernel_amd/
+LIB_PATH = Path(os.environ.get("PETIT_AMD_LIB", _PKG_ROOT / "lib" / "libpetit_amd.so"))
+
+PETIT_OK = 0
+PETIT_ERROR_PROBLEM_SHAPE = 1
+PETIT_ERROR_KERNEL_SHAPE = 2
+PETIT_ERROR_LAUNCH = 3
+PETIT_ERROR_BAD_ARGUMENT = 4
+PETIT_SOLUTION_AUTO = 0xFFFFFFFFFFFFFFFF
+
+# C++ DataType numbering of the reference (quantization/types.h:4-13)
+CXX_DTYPE_FP4_E2M1 = 3
+CXX_DTYPE_FP16 = 4
+CXX_DTYPE_BF16 = 5
+CXX_DTYPE_MXFP4_E2M1 = 7
+
+
+class SolutionHints(C.Structure):
+    """petit_solution_hints (include/petit_amd.h)."""
+    _fields_ = [("a_type", C.c_int32), ("b_type", C.c_int32), ("c_type", C.c_int32),
+                ("require_high_precision", C.c_int32)]
+
+
+# every symbol include/petit_amd.h declares, with its signature
+_SIGNATURES = {
+    "petit_gemm_fp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
+                                 [C.POINTER(SolutionHints), C.c_uint64, C.c_void_p]),
+    "petit_gemm_mxfp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
+                                   [C.POINTER(SolutionHints), C.c_uint64, C.c_void_p]),
+    "petit_gemm_get_solutions": (C.c_int, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint,
+                                           C.POINTER(C.c_uint64), C.POINTER(C.c_uint)]),
+    "petit_gemm_default_solution": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint]),
+    "petit_repack_nvfp4_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "petit_repack_nvfp4_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "petit_repack_mxfp4_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "petit_set_workspace": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
+    "petit_error_string": (C.c_char_p, [C.c_int]),
+    "petit_layout_tag": (C.c_char_p, []),
+    "petit_version": (C.c_char_p, []),
+    "petit_describe_solution": (C.c_int, [C.c_uint64, C.c_char_p, C.c_uint]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python petit-kernel_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def error_string(code: int) -> str:
+    return lib.petit_error_string(code).decode()
+
+
+def describe_solution(solution_id: int) -> str:
+    buf = C.create_string_buffer(256)
+    lib.petit_describe_solution(C.c_uint64(solution_id & PETIT_SOLUTION_AUTO), buf, 256)
+    return buf.value.decode()

@@ -1,0 +1,220 @@
+"""petit_kernel.ops -- the torch-facing operator layer.
+
+Mirrors the reference's pybind extension `petit_kernel.ops`
+(lib/pybind/pybind.cc:8-26, lib/pybind/fp4.cc): same function names, argument
+order and meaning, same output shapes / dtypes, same error classes
+(RuntimeError with the reference's message texts).  torch is used only for
+device memory and the current stream; the compute is libpetit_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SolutionHints as _CHints
+
+_LAYOUT_N = 16        # kLayoutN, fp4.cc:18
+_LAYOUT_M = 128       # kLayoutM, fp4.cc:17
+_PACK = 8             # kPackFactor, fp4.cc:19
+
+
+def _check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)  # what TORCH_CHECK / AT_ERROR surface as in Python
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _raise_on(code: int, what: str) -> None:
+    if code != _lib.PETIT_OK:
+        raise RuntimeError(f"{what}: {_lib.error_string(code)}")
+
+
+class PetitSolutionHints:
+    """PetitSolutionHints (quantization/gemm.h:112-117; bound at pybind.cc:19-25).
+
+    The reference binds the struct but never registers its enum type, so its
+    fields cannot actually be used from Python.
+    Here they accept a petit_kernel.DataType, a torch dtype or a raw C++ enum
+    integer.
+    """
+
+    def __init__(self) -> None:
+        self.a_type = None
+        self.b_type = None
+        self.c_type = None
+        self.require_high_precision = False
+
+    def __repr__(self) -> str:
+        return (f"PetitSolutionHints(a_type={self.a_type}, b_type={self.b_type}, "
+                f"c_type={self.c_type}, require_high_precision={self.require_high_precision})")
+
+
+def _cxx_dtype(x, default=None) -> int:
+    """Anything that names an element type -> the reference's C++ DataType value."""
+    if x is None:
+        if default is None:
+            raise RuntimeError("PetitSolutionHints field is not set")
+        return default
+    if isinstance(x, torch.dtype):
+        if x == torch.bfloat16:
+            return _lib.CXX_DTYPE_BF16
+        if x == torch.float16:
+            return _lib.CXX_DTYPE_FP16
+        raise RuntimeError("A must be bfloat16 or float16.")
+    name = getattr(x, "name", None)
+    if name is not None:  # petit_kernel.DataType (Python numbering, __init__.py:8-15)
+        table = {"float16": _lib.CXX_DTYPE_FP16, "bfloat16": _lib.CXX_DTYPE_BF16,
+                 "float4_e2m1": _lib.CXX_DTYPE_FP4_E2M1, "mxfloat4_e2m1": _lib.CXX_DTYPE_MXFP4_E2M1,
+                 "int4": 0, "float8_e4m3fn": 1, "float8_e5m2fn": 6}
+        return table[name]
+    return int(x)
+
+
+def _c_hints(h: PetitSolutionHints) -> _CHints:
+    a = _cxx_dtype(h.a_type)
+    return _CHints(a, _cxx_dtype(h.b_type, _lib.CXX_DTYPE_FP4_E2M1), _cxx_dtype(h.c_type, a),
+                   int(bool(h.require_high_precision)))
+
+
+def repack_nvfp4(b_q_weight: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """fp4.cc:38-78 (RepackNvFp4).  int32 [N, K/8] -> int32 [N/16, 2K]."""
+    _check(size_k % _LAYOUT_M == 0, f"size_k = {size_k} is not divisible by tile_k_size = {_LAYOUT_M}")
+    _check(size_n % _LAYOUT_N == 0, f"size_n = {size_n} is not divisible by tile_n_size = {_LAYOUT_N}")
+    _check(b_q_weight.dim() == 2 and size_k // _PACK == b_q_weight.size(1),
+           f"Shape mismatch: b_q_weight.size(1) = {b_q_weight.size(-1)}, size_k = {size_k}, pack_factor = {_PACK}")
+    _check(b_q_weight.size(0) == size_n, f"b_q_weight.size(0) = {b_q_weight.size(0)} is not size_n = {size_n}")
+    _check(b_q_weight.is_cuda, "b_q_weight is not on GPU")
+    _check(b_q_weight.is_contiguous(), "b_q_weight is not contiguous")
+    _check(b_q_weight.dtype == torch.int32, "b_q_weight type is not kInt")
+    out = torch.empty((size_n // _LAYOUT_N, size_k * _LAYOUT_N // _PACK), dtype=torch.int32,
+                      device=b_q_weight.device)
+    with torch.cuda.device(b_q_weight.device):
+        rc = _lib.lib.petit_repack_nvfp4_weights(_ptr(out), _ptr(b_q_weight), size_k, size_n, _stream(out))
+    _raise_on(rc, "repack_nvfp4")
+    return out
+
+
+def process_nvfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """fp4.cc:80-121 (ProcessNvFp4Scales).  e4m3 [N, K/16] -> e4m3 [N, K/16]."""
+    group_m = 2 * _LAYOUT_M
+    _check(size_k % group_m == 0, f"size_k = {size_k} is not divisible by tile_k_size = {group_m}")
+    _check(size_n % _LAYOUT_N == 0, f"size_n = {size_n} is not divisible by tile_n_size = {_LAYOUT_N}")
+    _check(scales.dim() == 2 and scales.size(1) > 0 and size_k // scales.size(1) == 16 and
+           size_k % scales.size(1) == 0, "Only groupsize = 16 is supported.")
+    _check(scales.size(0) == size_n, f"scales.size(0) = {scales.size(0)} is not size_n = {size_n}")
+    _check(scales.is_cuda, "scales is not on GPU")
+    _check(scales.is_contiguous(), "scales is not contiguous")
+    _check(scales.dtype == torch.float8_e4m3fn, "scales type is not float8_e4m3fn")
+    out = torch.empty((scales.size(0), scales.size(1)), dtype=scales.dtype, device=scales.device)
+    with torch.cuda.device(scales.device):
+        rc = _lib.lib.petit_repack_nvfp4_scales(_ptr(out), _ptr(scales), size_k, size_n, _stream(out))
+    _raise_on(rc, "process_nvfp4_scales")
+    return out
+
+
+def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """fp4.cc:123-161 (ProcessMxFp4Scales).  uint8 [N, K/32] -> uint8 [N/32, K]."""
+    group_m = 2 * _LAYOUT_M
+    _check(size_k % group_m == 0, f"size_k = {size_k} is not divisible by tile_k_size = {group_m}")
+    _check(size_n % _LAYOUT_N == 0, f"size_n = {size_n} is not divisible by tile_n_size = {_LAYOUT_N}")
+    _check(scales.dim() == 2 and scales.size(1) > 0 and size_k // scales.size(1) == 32 and
+           size_k % scales.size(1) == 0, "Only groupsize = 32 is supported.")
+    _check(scales.size(0) == size_n, f"scales.size(0) = {scales.size(0)} is not size_n = {size_n}")
+    _check(scales.is_cuda, "scales is not on GPU")
+    _check(scales.is_contiguous(), "scales is not contiguous")
+    _check(scales.dtype == torch.uint8, "scales type is not uint8")
+    # The reference computes size_n / 32 with integer division (fp4.cc:145-147) and
+    # would silently drop the last 16 rows; refuse instead.
+    _check(size_n % 32 == 0, f"size_n = {size_n} is not divisible by the MX scale tile (32)")
+    out = torch.empty((size_n // 32, size_k), dtype=scales.dtype, device=scales.device)
+    with torch.cuda.device(scales.device):
+        rc = _lib.lib.petit_repack_mxfp4_scales(_ptr(out), _ptr(scales), size_k, size_n, _stream(out))
+    _raise_on(rc, "process_mxfp4_scales")
+    return out
+
+
+def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id) -> torch.Tensor:
+    if A.dtype != torch.bfloat16 and A.dtype != torch.float16:
+        raise RuntimeError("A must be bfloat16 or float16.")
+    # Checks the reference leaves out but whose
+    # violation would read out of bounds:
+    _check(A.is_cuda and B.is_cuda and s.is_cuda and global_scale.is_cuda, "all tensors must be on GPU")
+    _check(A.is_contiguous() and A.numel() == size_m * size_k, "A must be a contiguous [size_m, size_k] tensor")
+    _check(B.is_contiguous() and B.numel() * B.element_size() == size_n * size_k // 2,
+           "B does not hold size_n * size_k packed 4-bit weights")
+    _check(global_scale.dtype == torch.float32 and global_scale.numel() >= 1, "global_scale must be float32")
+    c = torch.empty((size_m, size_n), dtype=A.dtype, device=A.device)
+    a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
+    b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
+    # require_high_precision: the reference turns it on for arch <= gfx90a when
+    # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
+    hints = _CHints(a_type, b_type, a_type, 0)
+    sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
+    fn = _lib.lib.petit_gemm_fp4_fp16_grid if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
+    with torch.cuda.device(A.device):
+        err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
+                 C.byref(hints), C.c_uint64(sid), _stream(A))
+    if err == _lib.PETIT_ERROR_PROBLEM_SHAPE:
+        raise RuntimeError(f"Incompatible problem shape (m={size_m}, n={size_n}, k={size_k})")
+    if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
+        raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
+    _raise_on(err, "mul_%sfp4_a16" % kind)
+    return c
+
+
+def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id) -> torch.Tensor:
+    """fp4.cc:163-209 (MulNvFp4A16)."""
+    if s.dim() != 2 or s.size(1) == 0 or size_k // s.size(1) != 16:
+        raise RuntimeError(f"Only groupsize = 16 is supported. size_k = {size_k}, s.size(1) = {s.size(-1)}")
+    _check(s.numel() == size_n * size_k // 16, "s does not hold size_n * size_k / 16 scales")
+    return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id)
+
+
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id) -> torch.Tensor:
+    """fp4.cc:211-260 (MulMxFp4A16)."""
+    _check(B.size(0) == size_n // _LAYOUT_N, f"B.size(0) = {B.size(0)} is not size_n / 16 = {size_n // _LAYOUT_N}")
+    _check(B.size(1) == size_k * _LAYOUT_N // _PACK,
+           f"B.size(1) = {B.size(1)} is not packed size = {size_k * _LAYOUT_N // _PACK}")
+    _check(s.size(0) == size_n // 32, f"s.size(0) = {s.size(0)} is not size_n / 32 = {size_n // 32}")
+    _check(s.size(1) == size_k, f"s.size(1) = {s.size(1)} is not size_k = {size_k}")
+    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id)
+
+
+def get_fp4_solutions(*args) -> list:
+    """fp4.cc:262-283 (GetNvFp4Solutions), bound twice (pybind.cc:14-17).
+
+    Accepts both call shapes that exist in the reference: the bound C++ order
+    `(hints, size_m, size_n, size_k)` and the Python wrapper's
+    `(size_m, size_n, size_k, a_type, c_type)` (petit_kernel/__init__.py:63-66),
+    which the reference itself cannot serve.
+    """
+    if len(args) == 4 and isinstance(args[0], PetitSolutionHints):
+        hints, m, n, k = args
+        ch = _c_hints(hints)
+    elif len(args) == 5:
+        m, n, k, a_type, c_type = args
+        a = _cxx_dtype(a_type)
+        ch = _CHints(a, _lib.CXX_DTYPE_FP4_E2M1, _cxx_dtype(c_type, a), 0)
+    else:
+        raise TypeError("get_fp4_solutions(hints, m, n, k) or get_fp4_solutions(m, n, k, a_type, c_type)")
+    count = C.c_uint(0)
+    err = _lib.lib.petit_gemm_get_solutions(C.byref(ch), m, n, k, None, C.byref(count))
+    if err != 0:
+        raise RuntimeError(f"Failed to get solutions: {err}")
+    buf = (C.c_uint64 * max(count.value, 1))()
+    err = _lib.lib.petit_gemm_get_solutions(C.byref(ch), m, n, k, buf, C.byref(count))
+    if err != 0:
+        raise RuntimeError(f"Failed to get solutions: {err}")
+    return [int(buf[i]) for i in range(count.value)]
+
+
+get_nvfp4_solutions = get_fp4_solutions
