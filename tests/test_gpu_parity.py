@@ -1,0 +1,293 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (via petit_kernel.ops,
+which is a ctypes shim), against the CPU oracle, the committed golden vectors and
+size-independent properties at BASELINE.json's full sizes.
+
+Tolerances
+  * repack: bit exact (byte movement).
+  * dequant (identity-activation GEMM): bit exact -- fp4 x scale needs <= 5 significant bits.
+  * GEMM: |c - ref| <= max(1e-2, 1e-2 * |ref|), the reference's own gtest bound
+    (fp4/gemm_fp4_fp16_rocm_test.cc:36,53) and BASELINE.json's "within 1e-2 rel-err"; the
+    reference's pytest uses the looser rtol = atol = 2e-2 (tests/ops/test_fp4_gemm_quark.py:54).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cdna4_layout as LY
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def pk():
+    import petit_kernel
+    assert torch.cuda.is_available()
+    name = torch.cuda.get_device_properties(0).gcnArchName
+    assert name.startswith("gfx950"), f"these kernels are gfx950 code objects, device is {name}"
+    return petit_kernel
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def from_bits(b: np.ndarray, dtype) -> torch.Tensor:
+    return torch.from_numpy(b.view(np.int16).copy()).view(dtype)
+
+
+def to_f32(b: np.ndarray, is_bf16: bool) -> np.ndarray:
+    return O.bf16_bits_to_f32(b) if is_bf16 else O.f16_bits_to_f32(b)
+
+
+def check_gemm(c_bits, ref_f32, is_bf16):
+    c = to_f32(c_bits, is_bf16).astype(np.float64)
+    ref = ref_f32.astype(np.float64)
+    fin = np.isfinite(ref) & (np.abs(ref) < (3.0e38 if is_bf16 else 6.0e4))
+    err = np.abs(c - ref)
+    bound = np.maximum(1e-2, 1e-2 * np.abs(ref))
+    assert np.isfinite(c[fin]).all()
+    assert (err[fin] <= bound[fin]).all(), f"max err {err[fin].max()} at ref {ref[fin][err[fin].argmax()]}"
+    # and much tighter on average: one 16-bit rounding of an f32-accumulated sum
+    rel = err[fin] / np.maximum(np.abs(ref[fin]), 1e-3)
+    assert np.median(rel) < (2 ** -8 if is_bf16 else 2 ** -11)
+
+
+def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1):
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    a = from_bits(a_bits, dtype).to(DEV)
+    qd = torch.from_numpy(q).to(DEV)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+    if kind == "nv":
+        b = pk.repack_nvfp4(qd.view(torch.int32), n, k)
+        sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+        c = pk.mul_nvfp4_a16(a, b, sp, gsd, m, n, k, solution_id)
+    else:
+        b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
+        sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+        c = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, solution_id)
+    torch.cuda.synchronize()
+    assert c.shape == (m, n) and c.dtype == dtype and c.is_cuda
+    return bits(c)
+
+
+# --- repack: bit exact against the layout model --------------------------------------
+
+@pytest.mark.parametrize("n,k", [(16, 256), (64, 256), (128, 512), (96, 768), (256, 1024), (8192, 8192)])
+def test_repack_bit_exact(pk, n, k):
+    rng = np.random.default_rng(n + k)
+    q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+    s = rng.integers(0, 256, (n, k // 16), dtype=np.uint8)
+    mx = rng.integers(0, 256, (n, k // 32), dtype=np.uint8)
+    b = pk.repack_nvfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+    assert b.shape == (n // 16, 2 * k) and b.dtype == torch.int32            # fp4.cc:62-63
+    want = LY.pack_weights(q.view(np.uint32).reshape(n, k // 8))
+    assert np.array_equal(b.cpu().numpy().view(np.uint32).ravel(), want)
+    sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+    assert sp.shape == (n, k // 16) and sp.dtype == torch.float8_e4m3fn       # fp4.cc:101-107
+    assert np.array_equal(sp.view(torch.uint8).cpu().numpy().ravel(), LY.pack_nvscales(s, k))
+    if n % 32 == 0:
+        mp = pk.process_mxfp4_scales(torch.from_numpy(mx).to(DEV), n, k)
+        assert mp.shape == (n // 32, k) and mp.dtype == torch.uint8          # fp4.cc:142-148
+        assert np.array_equal(mp.cpu().numpy().ravel(), LY.pack_mxscales(mx, k))
+    # repack_mxfp4 is the same weight shuffle (petit_kernel/__init__.py:27-28)
+    b2 = pk.repack_mxfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+    assert torch.equal(b, b2)
+
+
+# --- exhaustive dequant truth tables through the GEMM, bit exact ----------------------
+
+@pytest.mark.parametrize("is_bf16", [True, False])
+def test_exhaustive_nv_dequant_bit_exact(pk, golden_dir, is_bf16):
+    """16 codes x every positive e4m3 scale (ExhaustiveFp4DequantTest,
+    quantization_utils_fp4_test.cc:344-365) extracted with identity activations:
+    C[m][n] = W[n][m], one non-zero product per output, so the result must be exact."""
+    n, k = 128, 256
+    t = np.load(golden_dir / "dequant_tables.npz")["nv"]        # [16 codes, 126 scales]
+    code = np.arange(n)[:, None] % 16 * np.ones((1, k), dtype=np.int64)
+    code = (code + np.arange(k)[None, :]) % 16                  # every code in every nibble slot
+    q = (code[:, 0::2] | (code[:, 1::2] << 4)).astype(np.uint8)
+    sidx = (np.arange(n)[:, None] * 16 + np.arange(k // 16)[None, :]) % 126
+    s = (1 + sidx).astype(np.uint8)
+    want = t[code, np.repeat(sidx, 16, axis=1)]                 # f32 [n, k]
+    eye = np.eye(k, dtype=np.float32)
+    a_bits = O.f32_to_bf16_bits(eye) if is_bf16 else eye.astype(np.float16).view(np.uint16)
+    c = run_case(pk, "nv", a_bits, is_bf16, q, s, 1.0, k, n, k)
+    got = to_f32(c, is_bf16)                                    # [k, n] = W^T
+    assert np.array_equal(got.T, want)
+
+
+def test_exhaustive_mx_dequant_bit_exact(pk, golden_dir):
+    """16 codes x e8m0 1..237 with the reference's row/col-mixing scale generator
+    (MxFp4DequantTest, quantization_utils_fp4_test.cc:266-278,311-342)."""
+    n, k = 256, 256
+    t = np.load(golden_dir / "dequant_tables.npz")["mx"]        # [16, 237]
+    code = (np.arange(n)[:, None] + np.arange(k)[None, :]) % 16
+    q = (code[:, 0::2] | (code[:, 1::2] << 4)).astype(np.uint8)
+    sidx = (np.arange(k // 32)[None, :] + 29 * np.arange(n)[:, None]) % 237
+    s = (1 + sidx).astype(np.uint8)
+    want = t[code, np.repeat(sidx, 32, axis=1)]
+    a_bits = O.f32_to_bf16_bits(np.eye(k, dtype=np.float32))
+    c = run_case(pk, "mx", a_bits, True, q, s, 1.0, k, n, k)
+    got = to_f32(c, True)
+    assert np.array_equal(got.T, want)
+
+
+# --- the reference's pytest cases, from the committed golden vectors ------------------
+
+@pytest.mark.parametrize("name", ["nv_64_128_256_1234", "nv_96_64_512_2026",
+                                  "nv_64_128_256_1234_f16", "nv_96_64_512_2026_f16"])
+def test_nv_golden_cases(pk, golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    m, k = g["a"].shape
+    n = g["q"].shape[0]
+    is_bf16 = bool(g["a_is_bf16"])
+    c = run_case(pk, "nv", g["a"], is_bf16, g["q"], g["s"], float(g["gs"][0]), m, n, k)
+    check_gemm(c, to_f32(g["c_ref"], is_bf16), is_bf16)
+    # the reference pytest's own criterion (tests/ops/test_fp4_gemm_quark.py:54)
+    torch.testing.assert_close(torch.from_numpy(to_f32(c, is_bf16)), torch.from_numpy(to_f32(g["c_ref"], is_bf16)),
+                               rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("name", ["mx_64_128_256_1234", "mx_96_96_512_2026"])
+def test_mx_golden_cases(pk, golden_dir, name):
+    g = np.load(golden_dir / f"{name}.npz")
+    m, k = g["a"].shape
+    n = g["q"].shape[0]
+    c = run_case(pk, "mx", g["a"], True, g["q"], g["s"], float(g["gs"][0]), m, n, k)
+    ref = to_f32(g["c_ref"], True)
+    got = to_f32(c, True)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin)          # overflow to inf in the same places
+    assert np.array_equal(np.sign(got[~fin]), np.sign(ref[~fin]))
+    rel = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30)
+    assert rel.max() <= 1e-2
+
+
+def test_config1_golden(pk, golden_dir):
+    """BASELINE.json configs[0] (M=1, N=K=4096) against the reference-produced c_ref."""
+    from test_oracle import config1_inputs
+    g = np.load(golden_dir / "config1_nv_1_4096_4096.npz")
+    a, q, s, gs = config1_inputs()
+    c = run_case(pk, "nv", a, True, q, s, float(gs), 1, 4096, 4096)
+    check_gemm(c, to_f32(g["c_ref"], True), True)
+
+
+# --- seeded random problems against the oracle: shapes, dtypes, every solution ---------
+
+def random_problem(kind, m, n, k, seed, is_bf16, mx_band=None):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((m, k), dtype=np.float32)
+    a_bits = O.f32_to_bf16_bits(a) if is_bf16 else a.astype(np.float16).view(np.uint16)
+    q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+    if kind == "nv":
+        sf = rng.random((n, k // 16), dtype=np.float32) * 3.5 + 0.25
+        s = torch.from_numpy(sf).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    else:
+        lo, hi = mx_band or (119, 136)
+        s = rng.integers(lo, hi, (n, k // 32), dtype=np.uint8)
+    gs = float(rng.random() * 1.5 + 0.5)
+    return a_bits, q, s, gs
+
+
+def oracle_ref(kind, a_bits, is_bf16, q, s, gs):
+    dq = O.dequant_nvfp4(q, s) if kind == "nv" else O.dequant_mxfp4(q, s)
+    _, cf = O.gemm_ref(a_bits, is_bf16, dq, gs)
+    return cf
+
+
+SHAPES = [
+    # (m, n, k): ragged M, N % 16 only, every span size (K % 1024 / 512 / 256)
+    (1, 16, 256), (1, 64, 1024), (3, 48, 512), (7, 80, 768), (16, 128, 2048), (17, 64, 1024),
+    (33, 96, 1024), (64, 64, 2048), (100, 32, 256), (5, 4096, 4096), (130, 256, 1024),
+]
+
+
+@pytest.mark.parametrize("m,n,k", SHAPES)
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
+    if kind == "mx" and n % 32:
+        pytest.skip("MX scale tensor contract needs N % 32 (fp4.cc:145-147)")
+    a, q, s, gs = random_problem(kind, m, n, k, 1000 + m + n + k, is_bf16)
+    c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k)
+    check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256)])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
+    """The counterpart of the reference's one-gtest-per-tile-shape list
+    (fp4/gemm_fp4_fp16_rocm_test.cc:343-381): every enumerated kernel, same inputs."""
+    if kind == "mx" and n % 32:
+        pytest.skip("MX scale tensor contract needs N % 32")
+    a, q, s, gs = random_problem(kind, m, n, k, 77 + m + n + k, is_bf16)
+    ref = oracle_ref(kind, a, is_bf16, q, s, gs)
+    h = pk.PetitSolutionHints()
+    h.a_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.c_type = h.a_type
+    h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+    sols = pk.ops.get_fp4_solutions(h, m, n, k)
+    assert sols
+    for sid in sols:
+        c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid)
+        check_gemm(c, ref, is_bf16)
+
+
+def test_unknown_solution_and_bad_shapes_raise(pk):
+    a, q, s, gs = random_problem("nv", 1, 64, 256, 5, True)
+    with pytest.raises(RuntimeError, match="No kernel implementation for solution_id=4660"):
+        run_case(pk, "nv", a, True, q, s, gs, 1, 64, 256, 0x1234)
+    z = pk.mul_nvfp4_a16(torch.zeros((0, 256), dtype=torch.bfloat16, device=DEV),
+                         torch.zeros((4, 512), dtype=torch.int32, device=DEV),
+                         torch.zeros((64, 16), dtype=torch.float8_e4m3fn, device=DEV),
+                         torch.ones(1, device=DEV), 0, 64, 256, -1)
+    assert z.shape == (0, 64)                                    # gemm_fp4_fp16_grid.cc:42-44
+
+
+# --- BASELINE.json full sizes: oracle on the whole problem + size-independent properties --
+
+@pytest.mark.parametrize("m", [1, 16])
+def test_full_size_8192_vs_oracle(pk, m):
+    """configs[1]: M=1 (and 16), N=K=8192, bf16 x nvfp4, checked against the oracle on every
+    output (the C oracle does 8192^2 in about a second)."""
+    n = k = 8192
+    a, q, s, gs = random_problem("nv", m, n, k, 1234, True)
+    c = run_case(pk, "nv", a, True, q, s, gs, m, n, k)
+    check_gemm(c, oracle_ref("nv", a, True, q, s, gs), True)
+
+
+@pytest.mark.parametrize("n,k", [(10240, 8192), (8192, 28672)])
+def test_llama70b_shapes_properties(pk, n, k):
+    """configs[2] shapes (qkv, down): properties that need no reference at this size --
+    (1) zero activations give exactly zero; (2) a one-hot activation row reads back one
+    dequantised weight column exactly; (3) rows of a batch are independent: row i of an
+    M=8 call equals the M=1 call on that row, bit for bit; (4) sampled outputs vs the oracle."""
+    rng = np.random.default_rng(n ^ k)
+    _, q, s, gs = random_problem("nv", 1, n, k, 99, True)
+    qd = torch.from_numpy(q).to(DEV)
+    b = pk.repack_nvfp4(qd.view(torch.int32), n, k)
+    sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+    gsd = torch.tensor([1.0], dtype=torch.float32, device=DEV)
+    zero = torch.zeros((4, k), dtype=torch.bfloat16, device=DEV)
+    assert torch.count_nonzero(pk.mul_nvfp4_a16(zero, b, sp, gsd, 4, n, k, -1)) == 0
+    cols = [0, 1, 31, 32, 127, 128, 1023, 1024, k // 2 + 17, k - 1]
+    onehot = torch.zeros((len(cols), k), dtype=torch.bfloat16, device=DEV)
+    for i, c_ in enumerate(cols):
+        onehot[i, c_] = 1.0
+    got = pk.mul_nvfp4_a16(onehot, b, sp, gsd, len(cols), n, k, -1).float().cpu().numpy()
+    lut = O.FP4_VALUES
+    for i, c_ in enumerate(cols):
+        nib = (q[:, c_ // 2] >> (4 * (c_ % 2))) & 15
+        want = lut[nib] * O.e4m3_to_f32(s[:, c_ // 16])
+        assert np.array_equal(got[i], want)
+    a8 = torch.randn((8, k), dtype=torch.bfloat16, device=DEV)
+    c8 = pk.mul_nvfp4_a16(a8, b, sp, gsd, 8, n, k, -1)
+    for i in (0, 5):
+        c1 = pk.mul_nvfp4_a16(a8[i:i + 1].contiguous(), b, sp, gsd, 1, n, k, -1)
+        assert torch.equal(c1[0], c8[i])
+    rows = rng.integers(0, n, 64)
+    dq = O.dequant_nvfp4(q[rows], s[rows])
+    _, cf = O.gemm_ref(bits(a8), True, dq, 1.0)
+    check_gemm(bits(c8[:, torch.from_numpy(rows).to(DEV)]), cf, True)

@@ -1,0 +1,179 @@
+"""CPU tests of the host side: the packed-layout model, the C ABI surface and the Python
+operator layer's argument checking.  No compute call is made (there is no GPU here)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cdna4_layout as LY
+from oracle import oracle as O
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+@pytest.mark.parametrize("n,k", [(16, 256), (48, 512), (64, 1024), (32, 2048), (16, 768)])
+def test_layout_model_is_a_bijection_and_matches_index_functions(n, k):
+    rng = np.random.default_rng(n * 7 + k)
+    qw = rng.integers(0, 2 ** 32, (n, k // 8), dtype=np.uint64).astype(np.uint32)
+    pw = LY.pack_weights(qw)
+    assert np.array_equal(LY.unpack_weights(pw, n, k), qw)
+    for _ in range(300):
+        r, c = int(rng.integers(n)), int(rng.integers(k // 8))
+        assert pw[LY.weight_word_index(k, r, c)] == qw[r, c]
+    s = rng.integers(0, 256, (n, k // 16), dtype=np.uint8)
+    ps = LY.pack_nvscales(s, k)
+    assert np.array_equal(LY.unpack_nvscales(ps, n, k), s)
+    for _ in range(300):
+        r, c = int(rng.integers(n)), int(rng.integers(k // 16))
+        assert ps[LY.nvscale_byte_index(k, r, c)] == s[r, c]
+    m = rng.integers(0, 256, (n, k // 32), dtype=np.uint8)
+    pm = LY.pack_mxscales(m, k)
+    assert np.array_equal(LY.unpack_mxscales(pm, n, k), m)
+    for _ in range(300):
+        r, c = int(rng.integers(n)), int(rng.integers(k // 32))
+        assert pm[LY.mxscale_byte_index(k, r, c)] == m[r, c]
+
+
+def test_layout_keeps_the_reference_repack_invariant():
+    """dequant(unpack(pack(x))) == dequant(x): the reference's own acceptance test for a packed
+    format (quantization_utils_fp4_test.cc:103-133), applied to the gfx950 layout."""
+    n, k = 64, 1024
+    rng = np.random.default_rng(42)
+    q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+    s = rng.integers(1, 0x7F, (n, k // 16), dtype=np.uint8)
+    qw = q.view(np.uint32).reshape(n, k // 8)
+    q2 = LY.unpack_weights(LY.pack_weights(qw), n, k).view(np.uint8).reshape(n, k // 2)
+    s2 = LY.unpack_nvscales(LY.pack_nvscales(s, k), n, k)
+    assert np.array_equal(O.dequant_nvfp4(q2, s2).view(np.uint32), O.dequant_nvfp4(q, s).view(np.uint32))
+
+
+def test_span_tiles_rule_matches_layout_h():
+    text = (ROOT / "petit-kernel_amd/csrc/layout.h").read_text()
+    assert "(k % 1024u == 0) ? 8 : (k % 512u == 0) ? 4 : 2" in text
+    assert [LY.span_tiles_for_k(k) for k in (256, 512, 768, 1024, 4096, 28672, 1536)] == [2, 4, 2, 8, 8, 8, 4]
+
+
+# --- C ABI -------------------------------------------------------------------------
+
+def declared_symbols():
+    text = (ROOT / "include/petit_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(petit_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from petit_kernel import _lib
+    lib = C.CDLL(str(_lib.LIB_PATH))
+    syms = declared_symbols()
+    assert len(syms) >= 13
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in include/petit_amd.h but not exported"
+    assert set(_lib.EXPORTED_SYMBOLS) == set(syms)
+
+
+def test_cxx_header_compiles_against_the_c_abi(tmp_path):
+    """include/causalflow/petit/gemm.h (the reference's namespace API as inline wrappers)."""
+    import subprocess
+    src = tmp_path / "t.cc"
+    src.write_text('#include "causalflow/petit/gemm.h"\n'
+                   "using namespace causalflow::petit::rocm::quantization;\n"
+                   "int main() { PetitSolutionHints h{kDataTypeBf16, kDataTypeFp4e2m1, kDataTypeBf16, false};\n"
+                   "  unsigned n = 0; SolutionId ids[64];\n"
+                   "  if (fp4::GemmGetSolutions(h, 1, 8192, 8192, nullptr, &n) != 0) return 1;\n"
+                   "  if (n == 0 || n > 64) return 2; if (fp4::GemmGetSolutions(h, 1, 8192, 8192, ids, &n)) return 3;\n"
+                   "  static_assert(sizeof(SolutionId) == 8, \"\");\n"
+                   "  return ids[0].element_b == kMatmulTypeBNvFp4 && ids[0].mfma_type == kMatmulMfmaTypeBf16 ? 0 : 4; }\n")
+    from petit_kernel import _lib
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-I", str(ROOT / "include"), "-D__HIP_PLATFORM_AMD__",
+                    "-I/opt/rocm/include", str(src), "-o", str(exe), str(_lib.LIB_PATH),
+                    f"-Wl,-rpath,{_lib.LIB_PATH.parent}", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_solution_enumeration_and_ids():
+    from petit_kernel import _lib
+    import petit_kernel
+    sols = petit_kernel.get_fp4_solutions(1, 8192, 8192, torch.bfloat16, torch.bfloat16)
+    assert len(sols) == len(set(sols)) > 4
+    for s in sols:
+        assert (s >> 28) & 0xF == 1 and (s >> 32) & 0xF == 1  # element_b NvFp4, mfma bf16 (gemm.h:14-24)
+        assert (s >> 24) & 0xF == 3                           # Grid | HighPrecision (gemm.h:8-12)
+        assert "stream bf16xnvfp4" in _lib.describe_solution(s)
+    # both call shapes of the reference
+    h = petit_kernel.PetitSolutionHints()
+    h.a_type = petit_kernel.DataType.float16
+    h.b_type = petit_kernel.DataType.float4_e2m1
+    h.c_type = petit_kernel.DataType.float16
+    via_hints = petit_kernel.ops.get_fp4_solutions(h, 4, 4096, 4096)
+    assert via_hints == petit_kernel.get_fp4_solutions(4, 4096, 4096, torch.float16, torch.float16)
+    assert all((s >> 32) & 0xF == 0 for s in via_hints)
+    # K % 1024 != 0 selects the other span sizes; K % 256 != 0 has no solution
+    assert petit_kernel.get_fp4_solutions(1, 64, 768, torch.bfloat16, torch.bfloat16)
+    assert petit_kernel.get_fp4_solutions(1, 64, 384, torch.bfloat16, torch.bfloat16) == []
+    # non-FP4 b_type: -1 like algo_chooser.cc:20-23
+    bad = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, 0, _lib.CXX_DTYPE_BF16, 0)
+    cnt = C.c_uint(0)
+    assert _lib.lib.petit_gemm_get_solutions(C.byref(bad), 1, 64, 256, None, C.byref(cnt)) == -1
+    auto = _lib.lib.petit_gemm_default_solution(C.byref(_lib.SolutionHints(5, 3, 5, 0)), 1, 8192, 8192)
+    assert auto in sols
+
+
+def test_error_codes_without_a_gpu():
+    """Paths that return before any launch: zero sizes, bad shapes, unknown ids."""
+    from petit_kernel import _lib
+    h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    f = _lib.lib.petit_gemm_fp4_fp16_grid
+    one = C.c_void_p(16)  # never dereferenced on these paths
+    auto = C.c_uint64(_lib.PETIT_SOLUTION_AUTO)
+    assert f(one, one, one, one, one, 0, 64, 256, C.byref(h), auto, None) == 0  # gemm_fp4_fp16_grid.cc:42-44
+    assert f(one, one, one, one, one, 1, 0, 256, C.byref(h), auto, None) == 0
+    assert f(one, one, one, one, one, 1, 40, 256, C.byref(h), auto, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
+    assert f(one, one, one, one, one, 1, 64, 100, C.byref(h), auto, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
+    assert f(one, one, one, one, one, 1, 64, 256, C.byref(h), C.c_uint64(0x1234), None) == _lib.PETIT_ERROR_KERNEL_SHAPE
+    assert f(None, one, one, one, one, 1, 64, 256, C.byref(h), auto, None) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    hx = _lib.SolutionHints(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    assert f(one, one, one, one, one, 1, 64, 256, C.byref(hx), auto, None) == _lib.PETIT_ERROR_KERNEL_SHAPE
+    for fn in (_lib.lib.petit_repack_nvfp4_weights, _lib.lib.petit_repack_nvfp4_scales,
+               _lib.lib.petit_repack_mxfp4_scales):
+        assert fn(one, one, 0, 64, None) == 0
+        assert fn(one, one, 256, 24, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
+    assert _lib.lib.petit_repack_nvfp4_scales(one, one, 128, 16, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
+    assert _lib.error_string(1) == "incompatible problem shape"
+    assert _lib.lib.petit_layout_tag() == b"petit-cdna4/1"
+
+
+def test_python_layer_argument_checks():
+    """Same RuntimeError texts as the pybind layer (lib/pybind/fp4.cc:38-260)."""
+    import petit_kernel
+    qw = torch.zeros((64, 32), dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="size_k = 200 is not divisible by tile_k_size = 128"):
+        petit_kernel.repack_nvfp4(qw, 64, 200)
+    with pytest.raises(RuntimeError, match="size_n = 60 is not divisible by tile_n_size = 16"):
+        petit_kernel.repack_nvfp4(qw, 60, 256)
+    with pytest.raises(RuntimeError, match="b_q_weight is not on GPU"):
+        petit_kernel.repack_nvfp4(qw, 64, 256)
+    with pytest.raises(RuntimeError, match="Shape mismatch"):
+        petit_kernel.repack_nvfp4(qw, 64, 512)
+    s = torch.zeros((64, 16), dtype=torch.float8_e4m3fn)
+    with pytest.raises(RuntimeError, match="scales is not on GPU"):
+        petit_kernel.process_nvfp4_scales(s, 64, 256)
+    with pytest.raises(RuntimeError, match="Only groupsize = 16 is supported"):
+        petit_kernel.process_nvfp4_scales(s, 64, 512)
+    with pytest.raises(RuntimeError, match="tile_k_size = 256"):
+        petit_kernel.process_nvfp4_scales(s, 64, 128)
+    mx = torch.zeros((64, 8), dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="Only groupsize = 32 is supported"):
+        petit_kernel.process_mxfp4_scales(mx, 64, 512)
+    with pytest.raises(RuntimeError, match="scales is not on GPU"):
+        petit_kernel.process_mxfp4_scales(mx, 64, 256)
+    a = torch.zeros((1, 256), dtype=torch.float32)
+    with pytest.raises(RuntimeError, match="A must be bfloat16 or float16"):
+        petit_kernel.mul_nvfp4_a16(a, qw, s, torch.ones(1), 1, 64, 256, -1)
+    with pytest.raises(RuntimeError, match="Only groupsize = 16 is supported"):
+        petit_kernel.mul_nvfp4_a16(a.bfloat16(), qw, s, torch.ones(1), 1, 64, 512, -1)
+    assert [d.value for d in petit_kernel.DataType] == [0, 1, 2, 3, 4, 5, 6]  # __init__.py:8-15
