@@ -195,9 +195,11 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 //   NT    n-tiles (of 16) per wave
 //   WN,WK waves along N / K in the workgroup
 //   D     ring depth (tiles in flight per n-tile), D divides KS
-template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_> struct StreamCfg {
+//   ABL   ablation bits for tools/ablate (0 in every shipped kernel):
+//         1 no activation loads, 2 no unpack, 4 no MFMA, 8 empty kernel
+template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_, int ABL_ = 0> struct StreamCfg {
     using AT = AT_;
-    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_;
+    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_, ABL = ABL_;
     static constexpr int kThreads = 64 * WN * WK;
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(kThreads <= 1024, "workgroup too large");
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
     using AT = typename Cfg::AT;
     using Frag = typename AT::frag;
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT;
-    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D;
+    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, ABL = Cfg::ABL;
     constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
     // A voffset this large is out of range for every descriptor built below
     // whatever the generation's rule for soffset is (masked loads use soffset 0).
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         for (int nt = 0; nt < NT; ++nt)
             acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nt0 < ntiles && sp_begin < sp_end) {
+    if ((ABL & 8) == 0 && nt0 < ntiles && sp_begin < sp_end) {
         const unsigned valid_nt = min((unsigned)NT, ntiles - nt0);
         const unsigned w_row_bytes = ktiles * kTileBytes;             // one n-tile of W
         const unsigned s_row_bytes = (FMT == kFmtNv) ? p.k : p.k / 2; // one n-tile of scales
@@ -286,8 +288,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (ABL & 1)
+                    afrag[mt][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
+                else
+                    afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
+            }
 
         for (unsigned sp = sp_begin; sp < sp_end; ++sp) {
             const unsigned kt0 = sp * KS;
@@ -324,8 +330,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     for (int mt = 0; mt < MT; ++mt) {
                         const unsigned vo = ok ? a_voff[mt] : kOob;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            anext[mt][j] = buf_load16(a_rsrc, vo + j * 16, ok ? (kt + 1) * 256 : 0u, kAuxDefault);
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (ABL & 1)
+                                anext[mt][j] = afrag[mt][j];
+                            else
+                                anext[mt][j] = buf_load16(a_rsrc, vo + j * 16, ok ? (kt + 1) * 256 : 0u, kAuxDefault);
+                        }
                     }
                 }
 #pragma unroll
@@ -335,13 +345,21 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         Frag wf;
-                        if constexpr (FMT == kFmtNv)
+                        if constexpr (ABL & 2) {
+                            const unsigned w = wcur[nt][j], sb = __builtin_bit_cast(unsigned, j < 2 ? s_lo : s_hi);
+                            wf = __builtin_bit_cast(Frag, u32x4{w, w ^ sb, w, sb});
+                        } else if constexpr (FMT == kFmtNv)
                             wf = unpack_nv(AT{}, wcur[nt][j], j < 2 ? s_lo : s_hi);
                         else
                             wf = unpack_mx(AT{}, wcur[nt][j], s_lo);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            acc[mt][nt] = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), acc[mt][nt]);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if constexpr (ABL & 4) {
+                                const u32x4 wb = __builtin_bit_cast(u32x4, wf), ab = afrag[mt][j];
+                                acc[mt][nt] += __builtin_bit_cast(f32x4, wb ^ ab);
+                            } else
+                                acc[mt][nt] = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), acc[mt][nt]);
+                        }
                     }
                 }
 #pragma unroll
