@@ -55,8 +55,11 @@ bool family_for(int a_type, int b_type, Family *out) {
 
 bool shape_ok(unsigned n, unsigned k) { return n % kTileN == 0 && k % 256 == 0; }
 
-// Can this entry run (m, n, k)?  Only KS has to match the layout K implies.
-bool entry_fits(const SolutionEntry &e, unsigned k) { return e.shape.ks == span_tiles_for_k(k); }
+// Can this entry run (m, n, k)?  KS has to match the layout K implies, and the
+// staged-activation kernels hold at most AM rows.
+bool entry_fits(const SolutionEntry &e, unsigned m, unsigned k) {
+    return e.shape.ks == span_tiles_for_k(k) && (e.shape.am == 0 || m <= (unsigned)e.shape.am);
+}
 
 // Per-device registered split-K workspace.
 constexpr int kMaxDevices = 64;
@@ -90,11 +93,13 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     double best_score = -1.0;
     for (int i = 0; i < fam.count; ++i) {
         const SolutionEntry &e = fam.entries[i];
-        if (!entry_fits(e, k))
+        if (!entry_fits(e, m, k))
             continue;
         const StreamShape &s = e.shape;
         if (s.mt != (int)want_mt && !(m > 64 && s.mt == 4))
             continue;
+        if (m <= 4 && s.am == 0)
+            continue; // a staged-activation shape always exists for small M
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
         const unsigned waves = wgs * s.wn * s.wk;
         // waves that actually get a span
@@ -149,7 +154,7 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             entry = find_entry(fam, tuned);
             splitk = solution_splitk(tuned);
         }
-        if (entry && !entry_fits(*entry, k))
+        if (entry && !entry_fits(*entry, m, k))
             entry = nullptr;
         if (!entry) {
             entry = heuristic(fam, m, n, k);
@@ -161,7 +166,7 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         entry = find_entry(fam, solution_id);
         if (!entry)
             return kErrKernelShape;
-        if (!entry_fits(*entry, k))
+        if (!entry_fits(*entry, m, k))
             return kErrProblemShape;
         splitk = solution_splitk(solution_id);
         if (splitk == 0)
@@ -207,7 +212,6 @@ int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b
 
 int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
                              uint64_t *sols, unsigned *n_sols) {
-    (void)m;
     if (!hints || !n_sols)
         return -1;
     if (hints->b_type != kDataTypeFp4e2m1 && hints->b_type != kDataTypeMxFp4e2m1)
@@ -217,7 +221,7 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
     const unsigned cap = sols ? *n_sols : 0;
     if (hints->c_type == hints->a_type && family_for(hints->a_type, hints->b_type, &fam) && shape_ok(n, k)) {
         for (int i = 0; i < fam.count; ++i) {
-            if (!entry_fits(fam.entries[i], k))
+            if (!entry_fits(fam.entries[i], m, k))
                 continue;
             if (sols && count < cap)
                 sols[count] = make_solution_id(fam.entries[i].shape, fam.elem_b, fam.mfma, 1);
@@ -236,7 +240,7 @@ uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned
     uint64_t tuned = tuned_solution(current_device(), hints->a_type, hints->b_type, m, n, k);
     if (tuned) {
         const SolutionEntry *e = find_entry(fam, tuned);
-        if (e && entry_fits(*e, k))
+        if (e && entry_fits(*e, m, k))
             return tuned;
     }
     const SolutionEntry *e = heuristic(fam, m, n, k);
@@ -301,9 +305,10 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kErrKernelShape;
     }
     const StreamShape &s = e->shape;
-    snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d splitk%u  (wg tile %dx%d, %d threads)",
+    snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",
              a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
-             s.mt, s.nt, s.wn, s.wk, s.d, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * s.wk);
+             s.mt, s.nt, s.wn, s.wk, s.d, s.am, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
+             64 * s.wn * s.wk);
     return kOk;
 }
 

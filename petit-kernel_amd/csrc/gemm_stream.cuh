@@ -195,14 +195,29 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 //   NT    n-tiles (of 16) per wave
 //   WN,WK waves along N / K in the workgroup
 //   D     ring depth (tiles in flight per n-tile), D divides KS
+//   AM    activation path: 0 = fragment-shaped loads straight from L2 (any M);
+//         1, 2, 4 = the wave stages AM rows x one span of A in its private LDS
+//         slice with fully coalesced loads and reads MFMA fragments back with
+//         ds_read_b128 (M <= AM; needs MT == 1).  Measured on MI355X at M = 1,
+//         8192^2: the 36 four-lane buffer_loads per span of the direct path cost
+//         3 us of a 12 us launch (TA issue-bound), see DESIGN.md.
 //   ABL   ablation bits for tools/ablate (0 in every shipped kernel):
 //         1 no activation loads, 2 no unpack, 4 no MFMA, 8 empty kernel
-template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_, int ABL_ = 0> struct StreamCfg {
+template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_, int AM_ = 0, int ABL_ = 0>
+struct StreamCfg {
     using AT = AT_;
-    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_, ABL = ABL_;
+    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_, AM = AM_, ABL = ABL_;
     static constexpr int kThreads = 64 * WN * WK;
+    // one staged activation row: KS tiles x 256 B, padded by one 16-byte slot so
+    // that the rows a ds_read_b128 lane group touches fall on different banks
+    static constexpr int kARowU4 = KS * 16 + 1;
+    static constexpr int kALdsU4 = AM * kARowU4;                       // per wave
+    static constexpr int kRedItems = WN * MT * NT * 64;                // float4 outputs per workgroup
+    static constexpr int kSmemU4 = WN * WK * kALdsU4 + (WK > 1 ? WK * kRedItems : 0);
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(kThreads <= 1024, "workgroup too large");
+    static_assert(AM == 0 || (MT == 1 && (AM == 1 || AM == 2 || AM == 4)), "staged path: MT == 1, AM in {1,2,4}");
+    static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
 };
 
 template <class Cfg>
@@ -210,11 +225,14 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
     using AT = typename Cfg::AT;
     using Frag = typename AT::frag;
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT;
-    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, ABL = Cfg::ABL;
+    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, AM = Cfg::AM, ABL = Cfg::ABL;
     constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
     // A voffset this large is out of range for every descriptor built below
     // whatever the generation's rule for soffset is (masked loads use soffset 0).
     constexpr unsigned kOob = 0x80000000u;
+
+    // ONE LDS object: [per-wave activation slices][cross-wave reduction scratch]
+    __shared__ u32x4 smem[Cfg::kSmemU4 > 0 ? Cfg::kSmemU4 : 1];
 
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -269,7 +287,48 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 
         const unsigned kt_begin = sp_begin * KS, kt_end = sp_end * KS;
 
-        // --- prologue: fill the W ring, first scale records, first A fragments
+        // --- prologue: activations first (they are needed first), then scale
+        // records, then the W ring
+        u32x4 *const a_lds = smem + wave * Cfg::kALdsU4;               // staged path only
+        const unsigned a_frag_base = ((r < (unsigned)AM) ? r : 0u) * Cfg::kARowU4 + g * 4;
+        constexpr int kAStageLoads = AM * KS / 4;                      // 1 KiB per wave-load
+        u32x4 astage[kAStageLoads > 0 ? kAStageLoads : 1];             // next span, in flight
+        auto issue_a_stage = [&](unsigned sp, bool ok) {
+            if constexpr (AM > 0 && (ABL & 1) == 0) {
+#pragma unroll
+                for (int i = 0; i < kAStageLoads; ++i) {
+                    unsigned vo;
+                    if constexpr (KS >= 4) { // a row of the span is KS/4 whole wave-loads
+                        constexpr int kPerRow = KS / 4;
+                        vo = (i / kPerRow) * p.k * 2 + (i % kPerRow) * 1024 + lane * 16;
+                    } else { // KS == 2: one wave-load covers two rows of 512 B
+                        vo = (2 * i + (lane >> 5)) * p.k * 2 + (lane & 31u) * 16;
+                    }
+                    astage[i] = buf_load16(a_rsrc, ok ? vo : kOob, ok ? sp * (KS * 256) : 0u, kAuxDefault);
+                }
+            }
+        };
+        auto write_a_stage = [&]() {
+            if constexpr (AM > 0 && (ABL & 1) == 0) {
+#pragma unroll
+                for (int i = 0; i < kAStageLoads; ++i) {
+                    if constexpr (KS >= 4) {
+                        constexpr int kPerRow = KS / 4;
+                        a_lds[(i / kPerRow) * Cfg::kARowU4 + (i % kPerRow) * 64 + lane] = astage[i];
+                    } else {
+                        a_lds[(2 * i + (lane >> 5)) * Cfg::kARowU4 + (lane & 31u)] = astage[i];
+                    }
+                }
+            }
+        };
+        if constexpr (AM > 0) {
+            static_assert(AM * KS >= 4, "staged path needs at least one full wave-load per span");
+            issue_a_stage(sp_begin, true);
+        }
+        ScaleRec<FMT, KS> srec[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], sp_begin * 64 * kRecBytes);
         u32x4 wring[D][NT];
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -279,24 +338,27 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 wring[i][nt] = buf_load16(w_rsrc, ok ? w_voff[nt] : kOob,
                                           ok ? (kt_begin + i) * kTileBytes : 0u, kAuxNt);
             }
-        ScaleRec<FMT, KS> srec[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], sp_begin * 64 * kRecBytes);
 
         u32x4 afrag[MT][4];
+        if constexpr (AM == 0) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (ABL & 1)
-                    afrag[mt][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
-                else
-                    afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
-            }
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (ABL & 1)
+                        afrag[mt][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
+                    else
+                        afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
+                }
+        } else {
+            write_a_stage(); // first span's activations -> LDS
+        }
 
         for (unsigned sp = sp_begin; sp < sp_end; ++sp) {
             const unsigned kt0 = sp * KS;
+            // next span's activations (held in VGPRs until this span's fragments are read)
+            if constexpr (AM > 0)
+                issue_a_stage(sp + 1, sp + 1 < sp_end);
             // next span's scale records (masked past the end of this wave's range)
             ScaleRec<FMT, KS> srec_next[NT];
             {
@@ -322,9 +384,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                                                      ok ? (kt + D) * kTileBytes : 0u, kAuxNt);
                     }
                 }
-                // next step's activation fragments
+                // activation fragments: this step's from LDS (staged path), or the next
+                // step's straight from L2 (direct path)
                 u32x4 anext[MT][4];
-                {
+                if constexpr (AM > 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (ABL & 1)
+                            afrag[0][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
+                        else
+                            afrag[0][j] = a_lds[a_frag_base + T * 16 + j];
+                    }
+                } else {
                     const bool ok = kt + 1 < kt_end;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
@@ -362,12 +433,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                         }
                     }
                 }
+                if constexpr (AM == 0) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        afrag[mt][j] = anext[mt][j];
+                        for (int j = 0; j < 4; ++j)
+                            afrag[mt][j] = anext[mt][j];
+                }
             });
+            // every fragment of this span has been read (LDS is in order within a wave):
+            // the slice can take the next span's activations
+            if constexpr (AM > 0)
+                write_a_stage();
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 srec[nt] = srec_next[nt];
@@ -403,8 +480,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             for (int nt = 0; nt < NT; ++nt)
                 emit(acc[mt][nt], wn, mt, nt, lane);
     } else {
-        constexpr int kItems = WN * MT * NT * 64; // float4 outputs of the workgroup
-        __shared__ f32x4 red[WK * kItems];
+        constexpr int kItems = Cfg::kRedItems;
+        f32x4 *const red = reinterpret_cast<f32x4 *>(smem + WN * WK * Cfg::kALdsU4);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

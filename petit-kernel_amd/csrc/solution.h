@@ -15,7 +15,10 @@
 //   bits 36-39  warp_partition_m  1
 //   bits 40-43  warp_partition_n  WN
 //   bits 44-47  warp_partition_k  WK
-//   bits 48-51  warp_partition    0 (NK)
+//   bits 48-51  warp_partition    the reference's NK(0)/Cooperative(1) enum, never 1 in
+//                                 its shipped table; here: activation path,
+//                                 0 = direct L2 fragments, 1/2/3 = 1/2/4 rows staged
+//                                 through wave-private LDS (AM in gemm_stream.cuh)
 //   bits 52-55  [was padding]     NT  n-tiles per wave
 //   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
 //   bits 60-63  [was padding]     split-K across workgroups (gridDim.z), >= 1
@@ -33,14 +36,16 @@ enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u };
 enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u };
 
 struct StreamShape {
-    int ks, mt, nt, wn, wk, d;
+    int ks, mt, nt, wn, wk, d, am;
 };
+constexpr unsigned am_code(int am) { return am == 0 ? 0u : am == 1 ? 1u : am == 2 ? 2u : 3u; }
 
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {
     return (uint64_t)(s.mt & 0xff) | ((uint64_t)((s.wn * s.nt) & 0xff) << 8) |
            ((uint64_t)((2 * s.ks) & 0xff) << 16) | ((uint64_t)(kFeatGrid | kFeatHighPrecision) << 24) |
            ((uint64_t)(elem_b & 0xf) << 28) | ((uint64_t)(mfma & 0xf) << 32) | ((uint64_t)1 << 36) |
-           ((uint64_t)(s.wn & 0xf) << 40) | ((uint64_t)(s.wk & 0xf) << 44) | ((uint64_t)(s.nt & 0xf) << 52) |
+           ((uint64_t)(s.wn & 0xf) << 40) | ((uint64_t)(s.wk & 0xf) << 44) | ((uint64_t)am_code(s.am) << 48) |
+           ((uint64_t)(s.nt & 0xf) << 52) |
            ((uint64_t)(s.d & 0xf) << 56) | ((uint64_t)(splitk & 0xf) << 60);
 }
 constexpr unsigned solution_splitk(uint64_t id) { return (unsigned)(id >> 60) & 0xf; }
