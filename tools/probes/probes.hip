@@ -28,3 +28,51 @@ extern "C" void run_probe_cvt_scale(const unsigned *w, const float *s, float *of
 extern "C" void run_probe_buffer_oob(const unsigned *buf, unsigned num_bytes, unsigned voff, unsigned soff, unsigned *out, void *stream) {
     hipLaunchKernelGGL(probe_buffer_oob, dim3(1), dim3(64), 0, (hipStream_t)stream, buf, num_bytes, voff, soff, out);
 }
+
+// launch-floor probe: an empty kernel at a given grid/block, and a pure streaming read
+// (nt dwordx4, `per_thread` loads in flight per thread, grid-stride) summing into a sink.
+__global__ void probe_empty(unsigned *sink) {
+    if (threadIdx.x == 0xffffffffu) sink[0] = 1;
+}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int PER> __global__ void probe_stream(const u32x4 *src, size_t n16, unsigned *sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; i + (PER - 1) * stride < n16; i += PER * stride) {
+        u32x4 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc ^= v[j];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[threadIdx.x] = acc.x;
+}
+// contiguous-per-wave variant: each wave reads `PER` consecutive KiB (like the GEMM's tiles)
+template <int PER> __global__ void probe_stream_wave(const u32x4 *src, size_t n16, unsigned *sink) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned lane = threadIdx.x & 63;
+    const size_t base = wave * (size_t)PER * 64 + lane;
+    u32x4 acc = {0, 0, 0, 0};
+    if (base + (PER - 1) * 64 < n16) {
+        u32x4 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = __builtin_nontemporal_load(src + base + j * 64);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc ^= v[j];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[threadIdx.x] = acc.x;
+}
+extern "C" void run_probe_empty(unsigned grid, unsigned block, unsigned *sink, void *stream) {
+    hipLaunchKernelGGL(probe_empty, dim3(grid), dim3(block), 0, (hipStream_t)stream, sink);
+}
+extern "C" void run_probe_stream(int kind, int per, unsigned grid, unsigned block, const void *src, size_t bytes,
+                                 unsigned *sink, void *stream) {
+    const u32x4 *s = (const u32x4 *)src;
+    const size_t n16 = bytes / 16;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(K, P)                                                                                        \
+    if (kind == 0 && per == P) hipLaunchKernelGGL(probe_stream<P>, dim3(grid), dim3(block), 0, st, s, n16, sink); \
+    if (kind == 1 && per == P) hipLaunchKernelGGL(probe_stream_wave<P>, dim3(grid), dim3(block), 0, st, s, n16, sink);
+    GO(0, 1) GO(0, 2) GO(0, 4) GO(0, 8) GO(0, 16)
+}
