@@ -247,18 +247,22 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 
     // K range of this wave: contiguous spans.  gridDim.z splits K across
     // workgroups first, WK across the waves of a workgroup second.
-    const unsigned kparts = gridDim.z * WK;
     const unsigned part = blockIdx.z * WK + wk;
-    const unsigned chunk = (nspans + kparts - 1) / kparts;
+    const unsigned chunk = p.spans_per_wave; // ceil(nspans / (gridDim.z * WK)), computed on the host
     const unsigned sp_begin = min(part * chunk, nspans);
     const unsigned sp_end = min(sp_begin + chunk, nspans);
 
-    f32x4 acc[MT][NT];
+    // two accumulators per output tile (even / odd MFMA of a tile) when registers
+    // allow, so consecutive MFMAs do not wait on each other's result
+    constexpr int NACC = (MT * NT <= 2) ? 2 : 1;
+    f32x4 acc[MT][NT][NACC];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NACC; ++q)
+                acc[mt][nt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if ((ABL & 8) == 0 && nt0 < ntiles && sp_begin < sp_end) {
         const unsigned valid_nt = min((unsigned)NT, ntiles - nt0);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         for (int mt = 0; mt < MT; ++mt)
             a_voff[mt] = ((mt * 16 + r) * p.k + g * kLaneK) * 2; // rows >= M fall out of range
 
-        const unsigned kt_begin = sp_begin * KS, kt_end = sp_end * KS;
+        const unsigned kt_begin = sp_begin * KS;
 
         // --- prologue: activations first (they are needed first), then scale
         // records, then the W ring
@@ -294,6 +298,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         constexpr int kAStageLoads = AM * KS / 4;                      // 1 KiB per wave-load
         u32x4 astage[kAStageLoads > 0 ? kAStageLoads : 1];             // next span, in flight
         auto issue_a_stage = [&](unsigned sp, bool ok) {
+            (void)ok;
             if constexpr (AM > 0 && (ABL & 1) == 0) {
 #pragma unroll
                 for (int i = 0; i < kAStageLoads; ++i) {
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     } else { // KS == 2: one wave-load covers two rows of 512 B
                         vo = (2 * i + (lane >> 5)) * p.k * 2 + (lane & 31u) * 16;
                     }
-                    astage[i] = buf_load16(a_rsrc, ok ? vo : kOob, ok ? sp * (KS * 256) : 0u, kAuxDefault);
+                    astage[i] = buf_load16(a_rsrc, vo, sp * (KS * 256), kAuxDefault);
                 }
             }
         };
@@ -333,11 +338,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const bool ok = kt_begin + i < kt_end;
-                wring[i][nt] = buf_load16(w_rsrc, ok ? w_voff[nt] : kOob,
-                                          ok ? (kt_begin + i) * kTileBytes : 0u, kAuxNt);
-            }
+            for (int nt = 0; nt < NT; ++nt) // D <= KS tiles always exist
+                wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxNt);
 
         u32x4 afrag[MT][4];
         if constexpr (AM == 0) {
@@ -354,36 +356,29 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             write_a_stage(); // first span's activations -> LDS
         }
 
-        for (unsigned sp = sp_begin; sp < sp_end; ++sp) {
+        // One span (KS tiles).  kLast: the wave's final span -- nothing further is
+        // prefetched, so a wave that owns a single span issues exactly the loads it
+        // uses.  Within a step the order is: read this tile's fragments, unpack +
+        // MFMA out of ring slot T % D, THEN refill that slot D tiles ahead; the
+        // sched_barrier pins that order (hipcc otherwise sinks every refill to the end
+        // of the span and copies the ring at the back edge, draining the pipeline).
+        ScaleRec<FMT, KS> srec_next[NT];
+        auto span_body = [&](const unsigned sp, auto last_c) {
+            constexpr bool kLast = decltype(last_c)::value;
             const unsigned kt0 = sp * KS;
-            // next span's activations (held in VGPRs until this span's fragments are read)
-            if constexpr (AM > 0)
-                issue_a_stage(sp + 1, sp + 1 < sp_end);
-            // next span's scale records (masked past the end of this wave's range)
-            ScaleRec<FMT, KS> srec_next[NT];
-            {
-                const bool ok = sp + 1 < sp_end;
+            if constexpr (!kLast) {
+                if constexpr (AM > 0)
+                    issue_a_stage(sp + 1, true); // held in VGPRs until this span's fragments are read
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    srec_next[nt] = load_scale_rec<FMT, KS>(s_rsrc, ok ? s_voff[nt] : kOob,
-                                                            ok ? (sp + 1) * 64 * kRecBytes : 0u);
+                    srec_next[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], (sp + 1) * 64 * kRecBytes);
             }
-
             static_for<0, KS>([&](auto t_c) {
                 constexpr int T = decltype(t_c)::value;
                 constexpr int SLOT = T % D;
+                constexpr bool kRefill = !kLast || (T + D < KS);
+                constexpr bool kNextA = !kLast || (T + 1 < KS);
                 const unsigned kt = kt0 + T;
-                // take this step's tiles out of the ring, refill the slot D steps ahead
-                u32x4 wcur[NT];
-                {
-                    const bool ok = kt + D < kt_end;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        wcur[nt] = wring[SLOT][nt];
-                        wring[SLOT][nt] = buf_load16(w_rsrc, ok ? w_voff[nt] : kOob,
-                                                     ok ? (kt + D) * kTileBytes : 0u, kAuxNt);
-                    }
-                }
                 // activation fragments: this step's from LDS (staged path), or the next
                 // step's straight from L2 (direct path)
                 u32x4 anext[MT][4];
@@ -395,19 +390,16 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                         else
                             afrag[0][j] = a_lds[a_frag_base + T * 16 + j];
                     }
-                } else {
-                    const bool ok = kt + 1 < kt_end;
+                } else if constexpr (kNextA) {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const unsigned vo = ok ? a_voff[mt] : kOob;
+                    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if constexpr (ABL & 1)
                                 anext[mt][j] = afrag[mt][j];
                             else
-                                anext[mt][j] = buf_load16(a_rsrc, vo + j * 16, ok ? (kt + 1) * 256 : 0u, kAuxDefault);
+                                anext[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt + 1) * 256, kAuxDefault);
                         }
-                    }
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -415,40 +407,53 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     tile_scales<FMT, KS, T>(srec[nt], s_lo, s_hi);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
+                        const unsigned w = wring[SLOT][nt][j];
                         Frag wf;
                         if constexpr (ABL & 2) {
-                            const unsigned w = wcur[nt][j], sb = __builtin_bit_cast(unsigned, j < 2 ? s_lo : s_hi);
+                            const unsigned sb = __builtin_bit_cast(unsigned, j < 2 ? s_lo : s_hi);
                             wf = __builtin_bit_cast(Frag, u32x4{w, w ^ sb, w, sb});
                         } else if constexpr (FMT == kFmtNv)
-                            wf = unpack_nv(AT{}, wcur[nt][j], j < 2 ? s_lo : s_hi);
+                            wf = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
                         else
-                            wf = unpack_mx(AT{}, wcur[nt][j], s_lo);
+                            wf = unpack_mx(AT{}, w, s_lo);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
+                            f32x4 &a = acc[mt][nt][j % NACC];
                             if constexpr (ABL & 4) {
                                 const u32x4 wb = __builtin_bit_cast(u32x4, wf), ab = afrag[mt][j];
-                                acc[mt][nt] += __builtin_bit_cast(f32x4, wb ^ ab);
+                                a += __builtin_bit_cast(f32x4, wb ^ ab);
                             } else
-                                acc[mt][nt] = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), acc[mt][nt]);
+                                a = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), a);
                         }
                     }
                 }
-                if constexpr (AM == 0) {
+                if constexpr (kRefill) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxNt);
+                }
+                if constexpr (AM == 0 && kNextA) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             afrag[mt][j] = anext[mt][j];
                 }
+                __builtin_amdgcn_sched_barrier(0);
             });
-            // every fragment of this span has been read (LDS is in order within a wave):
-            // the slice can take the next span's activations
-            if constexpr (AM > 0)
-                write_a_stage();
+            if constexpr (!kLast) {
+                // every fragment of this span has been read (LDS is in order within a
+                // wave): the slice can take the next span's activations
+                if constexpr (AM > 0)
+                    write_a_stage();
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                srec[nt] = srec_next[nt];
-        }
+                for (int nt = 0; nt < NT; ++nt)
+                    srec[nt] = srec_next[nt];
+            }
+        };
+        for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+            span_body(sp, std::false_type{});
+        span_body(sp_end - 1, std::true_type{});
     }
 
     // --- cross-wave K reduction through LDS, then the epilogue -----------------
@@ -473,12 +478,21 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         }
     };
 
+    f32x4 accs[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            accs[mt][nt] = acc[mt][nt][0];
+            if constexpr (NACC == 2)
+                accs[mt][nt] += acc[mt][nt][1];
+        }
     if constexpr (WK == 1) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                emit(acc[mt][nt], wn, mt, nt, lane);
+                emit(accs[mt][nt], wn, mt, nt, lane);
     } else {
         constexpr int kItems = Cfg::kRedItems;
         f32x4 *const red = reinterpret_cast<f32x4 *>(smem + WN * WK * Cfg::kALdsU4);
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                red[wk * kItems + ((wn * MT + mt) * NT + nt) * 64 + lane] = acc[mt][nt];
+                red[wk * kItems + ((wn * MT + mt) * NT + nt) * 64 + lane] = accs[mt][nt];
         __syncthreads();
         for (unsigned item = threadIdx.x; item < (unsigned)kItems; item += Cfg::kThreads) {
             f32x4 v = red[item];

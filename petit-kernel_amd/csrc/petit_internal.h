@@ -40,6 +40,7 @@ struct GemmArgs {
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
     unsigned *counters; // split-K arrival tickets (may be null when splitk == 1)
     unsigned m, n, k;
+    unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))
 };
 
 // repack.hip

@@ -7,7 +7,9 @@ template <int MT, int NT, int WN, int WK, int D, int AM, int ABL> static void la
     using Cfg = StreamCfg<Bf16, kFmtNv, 8, MT, NT, WN, WK, D, AM, ABL>;
     const unsigned ntiles = a.n / 16, per_wg = WN * NT;
     dim3 grid((ntiles + per_wg - 1) / per_wg, (a.m + 16 * MT - 1) / (16 * MT), 1);
-    hipLaunchKernelGGL(gemm_stream_kernel<Cfg>, grid, dim3(Cfg::kThreads), 0, st, a);
+    GemmArgs b = a;
+    b.spans_per_wave = (a.k / 1024 + WK - 1) / WK;
+    hipLaunchKernelGGL(gemm_stream_kernel<Cfg>, grid, dim3(Cfg::kThreads), 0, st, b);
 }
 
 // variant: (MT,NT,WN,WK,D,AM) 0 = (1,1,1,8,8,1) 1 = (1,1,1,8,4,1) 2 = (1,1,1,8,8,4) 3 = (1,2,1,8,4,0)
