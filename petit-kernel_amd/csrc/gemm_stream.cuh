@@ -84,17 +84,19 @@ template <int SEL> __device__ __forceinline__ f16x2 cvt_fp4_f16(unsigned w, floa
     return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, scale, SEL);
 }
 
-// NVFP4 -> bf16: exact (fp4 x e4m3 needs <= 5 significant bits).
+// NVFP4 -> bf16: exact (fp4 x e4m3 needs <= 5 significant bits), so the f32
+// products are turned into bf16 by TRUNCATION -- one v_perm_b32 per pair picking
+// the two high halves -- instead of v_cvt_pk_bf16_f32, which measures ~10 cycles
+// per wave-instruction on gfx950 against 4 for v_perm_b32 (tools/probes/valu_rate).
+__device__ __forceinline__ unsigned trunc_pack_bf16(f32x2 p) {
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, p.y), __builtin_bit_cast(unsigned, p.x), 0x07060302u);
+}
 __device__ __forceinline__ bf16x8 unpack_nv(Bf16, unsigned w, float s) {
-    f32x2 p0 = cvt_fp4_f32<0>(w, 1.0f) * s;
-    f32x2 p1 = cvt_fp4_f32<1>(w, 1.0f) * s;
-    f32x2 p2 = cvt_fp4_f32<2>(w, 1.0f) * s;
-    f32x2 p3 = cvt_fp4_f32<3>(w, 1.0f) * s;
-    bf16x2 q0 = __builtin_convertvector(p0, bf16x2);
-    bf16x2 q1 = __builtin_convertvector(p1, bf16x2);
-    bf16x2 q2 = __builtin_convertvector(p2, bf16x2);
-    bf16x2 q3 = __builtin_convertvector(p3, bf16x2);
-    return bf16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+    const f32x2 p0 = cvt_fp4_f32<0>(w, 1.0f) * s;
+    const f32x2 p1 = cvt_fp4_f32<1>(w, 1.0f) * s;
+    const f32x2 p2 = cvt_fp4_f32<2>(w, 1.0f) * s;
+    const f32x2 p3 = cvt_fp4_f32<3>(w, 1.0f) * s;
+    return __builtin_bit_cast(bf16x8, u32x4{trunc_pack_bf16(p0), trunc_pack_bf16(p1), trunc_pack_bf16(p2), trunc_pack_bf16(p3)});
 }
 // NVFP4 -> fp16: exact (|fp4 * s| <= 2688, >= 2^-10).
 __device__ __forceinline__ f16x8 unpack_nv(Fp16, unsigned w, float s) {
