@@ -88,12 +88,14 @@ template <int SEL> __device__ __forceinline__ f16x2 cvt_fp4_f16(unsigned w, floa
 // products are turned into bf16 by TRUNCATION -- one v_perm_b32 per pair picking
 // the two high halves -- instead of v_cvt_pk_bf16_f32, which measures ~10 cycles
 // per wave-instruction on gfx950 against 4 for v_perm_b32 (tools/probes/valu_rate).
-// (inline asm on purpose: hipcc/ROCm 7.2 miscompiles __builtin_amdgcn_perm when both
-// operands are the two halves of one 64-bit vector -- it emits v_perm_b32 d, x, x.)
+// hipcc/ROCm 7.2 miscompiles __builtin_amdgcn_perm when it can see that both
+// operands are the halves of one 64-bit vector (it emits v_perm_b32 d, x, x); the
+// empty asm hides that relation.  A real asm v_perm would need its own VALU->MFMA
+// wait states, which the compiler only inserts for instructions it can see.
 __device__ __forceinline__ unsigned trunc_pack_bf16(f32x2 p) {
-    unsigned r;
-    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(p.y), "v"(p.x), "s"(0x07060302u));
-    return r;
+    float x = p.x, y = p.y;
+    asm("" : "+v"(y));
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y), __builtin_bit_cast(unsigned, x), 0x07060302u);
 }
 __device__ __forceinline__ bf16x8 unpack_nv(Bf16, unsigned w, float s) {
     const f32x2 p0 = cvt_fp4_f32<0>(w, 1.0f) * s;
