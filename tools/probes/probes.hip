@@ -63,6 +63,21 @@ template <int PER> __global__ void probe_stream_wave(const u32x4 *src, size_t n1
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[threadIdx.x] = acc.x;
 }
+// workgroup-interleaved variant: the G waves of a workgroup own G*PER consecutive KiB; at step j
+// wave i reads KiB (j*G + i) of that block, so the workgroup's concurrent loads are contiguous.
+template <int PER> __global__ void probe_stream_wgil(const u32x4 *src, size_t n16, unsigned *sink) {
+    const unsigned G = blockDim.x >> 6, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t base = (size_t)blockIdx.x * G * PER * 64 + (size_t)wv * 64 + lane;
+    u32x4 acc = {0, 0, 0, 0};
+    if (base + (size_t)(PER - 1) * G * 64 < n16) {
+        u32x4 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = __builtin_nontemporal_load(src + base + (size_t)j * G * 64);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) acc ^= v[j];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[threadIdx.x] = acc.x;
+}
 extern "C" void run_probe_empty(unsigned grid, unsigned block, unsigned *sink, void *stream) {
     hipLaunchKernelGGL(probe_empty, dim3(grid), dim3(block), 0, (hipStream_t)stream, sink);
 }
@@ -73,6 +88,7 @@ extern "C" void run_probe_stream(int kind, int per, unsigned grid, unsigned bloc
     hipStream_t st = (hipStream_t)stream;
 #define GO(K, P)                                                                                        \
     if (kind == 0 && per == P) hipLaunchKernelGGL(probe_stream<P>, dim3(grid), dim3(block), 0, st, s, n16, sink); \
-    if (kind == 1 && per == P) hipLaunchKernelGGL(probe_stream_wave<P>, dim3(grid), dim3(block), 0, st, s, n16, sink);
+    if (kind == 1 && per == P) hipLaunchKernelGGL(probe_stream_wave<P>, dim3(grid), dim3(block), 0, st, s, n16, sink); \
+    if (kind == 2 && per == P) hipLaunchKernelGGL(probe_stream_wgil<P>, dim3(grid), dim3(block), 0, st, s, n16, sink);
     GO(0, 1) GO(0, 2) GO(0, 4) GO(0, 8) GO(0, 16)
 }

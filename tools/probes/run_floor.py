@@ -35,8 +35,7 @@ def timeit(fn, launches=200, reps=5):
 
 
 out = {"empty": {}, "stream": {}}
-for grid, block in [(1, 64), (256, 64), (256, 256), (256, 512), (256, 1024), (512, 256), (512, 512), (1024, 256),
-                    (2048, 256), (4096, 64), (4096, 256)]:
+for grid, block in [(1, 64), (512, 512)]:
     us = timeit(lambda i: lib.run_probe_empty(grid, block, C.c_void_p(sink.data_ptr()),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     out["empty"][f"{grid}x{block}"] = us
@@ -45,10 +44,10 @@ for grid, block in [(1, 64), (256, 64), (256, 256), (256, 512), (256, 1024), (51
 nbytes = 37781504 // 1024 * 1024
 copies = 10
 bufs = [torch.randint(-2 ** 31, 2 ** 31 - 1, (nbytes // 4,), dtype=torch.int32, device=dev) for _ in range(copies)]
-for kind, per, grid, block in [(0, 4, 2048, 256), (0, 8, 1024, 256), (0, 8, 2048, 256), (0, 16, 512, 256), (0, 2, 4096, 256),
-                               (1, 8, 512, 512), (1, 8, 1024, 256), (1, 4, 1024, 512), (1, 4, 2048, 256), (1, 16, 512, 256),
-                               (1, 16, 256, 512), (1, 2, 2048, 512), (1, 1, 4096, 512)]:
-    if kind == 1:  # grid must cover the buffer exactly: waves * per KiB
+for kind, per, grid, block in [(0, 16, 512, 256), (0, 2, 4096, 256), (0, 4, 2048, 256), (0, 8, 576, 512), (0, 8, 1152, 256),
+                               (1, 8, 0, 512), (1, 8, 0, 256), (2, 8, 0, 512), (2, 8, 0, 256), (2, 8, 0, 1024),
+                               (2, 4, 0, 512), (2, 16, 0, 256), (2, 16, 0, 512), (1, 8, 0, 512), (2, 8, 0, 512)]:
+    if kind >= 1:  # grid must cover the buffer exactly: waves * per KiB
         waves = nbytes // (per * 1024)
         grid = (waves * 64 + block - 1) // block
     us = timeit(lambda i: lib.run_probe_stream(kind, per, grid, block, bufs[i % copies].data_ptr(), nbytes,
