@@ -360,8 +360,19 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     else
                         afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
                 }
-        } else {
+        }
+        auto load_first_frags = [&]() { // fragments of tile 0 of the span now in LDS
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (ABL & 1)
+                    afrag[0][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
+                else
+                    afrag[0][j] = a_lds[a_frag_base + j];
+            }
+        };
+        if constexpr (AM > 0) {
             write_a_stage(); // first span's activations -> LDS
+            load_first_frags();
         }
 
         // One span (KS tiles).  kLast: the wave's final span -- nothing further is
@@ -391,12 +402,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 // step's straight from L2 (direct path)
                 u32x4 anext[MT][4];
                 if constexpr (AM > 0) {
+                    // staged path: prefetch the NEXT tile's fragments now, so the LDS
+                    // latency hides behind this tile's unpack instead of stalling each MFMA
+                    if constexpr (T + 1 < KS) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if constexpr (ABL & 1)
-                            afrag[0][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
-                        else
-                            afrag[0][j] = a_lds[a_frag_base + T * 16 + j];
+                        for (int j = 0; j < 4; ++j)
+                            anext[0][j] = (ABL & 1) ? afrag[0][j] : a_lds[a_frag_base + (T + 1) * 16 + j];
+                        __builtin_amdgcn_sched_barrier(0); // keep the reads at the top of the step
                     }
                 } else if constexpr (kNextA) {
 #pragma unroll
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     for (int nt = 0; nt < NT; ++nt)
                         wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxNt);
                 }
-                if constexpr (AM == 0 && kNextA) {
+                if constexpr ((AM == 0 && kNextA) || (AM > 0 && T + 1 < KS)) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -452,8 +464,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             if constexpr (!kLast) {
                 // every fragment of this span has been read (LDS is in order within a
                 // wave): the slice can take the next span's activations
-                if constexpr (AM > 0)
+                if constexpr (AM > 0) {
                     write_a_stage();
+                    load_first_frags();
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     srec[nt] = srec_next[nt];
