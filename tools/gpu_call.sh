@@ -1,5 +1,10 @@
 mkdir -p gpurun_out
-(timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > gpurun_out/r1_tests.log
-timeout 900 python tools/tune.py --shapes sq8192,sq4096,gate_up,down --ms 1,4 --out gpurun_out/tune_e.json > gpurun_out/tune_e.log 2>&1
-timeout 300 python tools/ablate/run_ablate.py 1 > gpurun_out/ablate_e.log 2>&1
-tail -2 gpurun_out/r1_tests.log; grep -v amdgpu.ids gpurun_out/tune_e.log | tail -9; grep -v amdgpu.ids gpurun_out/ablate_e.log | grep "variant 0"
+timeout 900 python tools/tune.py --shapes sq8192,gate_up --ms 1 --out gpurun_out/tune_f.json > gpurun_out/tune_f.log 2>&1
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/tune_f.json'))
+for e in d['results']:
+    print(e['shape'], 'M=',e['m'])
+    for r in e['results']:
+        if 'us_median' in r: print('   %7.2f us  %5.0f GB/s  %s'%(r['us_median'], r['gbs'], r['desc'][18:56]))
+PY
