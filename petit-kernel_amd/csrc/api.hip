@@ -85,37 +85,48 @@ uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
 // (The reference's heuristic ignores the CU count altogether and leaves half of
 // a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
 const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k) {
+    // Rules distilled from the MI355X sweeps (profiles/):
+    //  * M <= 4: stage the activations through LDS (AM = smallest that holds M);
+    //  * what saturates HBM is bytes in flight: as many resident waves as the grid
+    //    allows, every wave with its whole ring outstanding -> pick the shape whose
+    //    wave count is closest to (but preferably above) 4 waves per SIMD;
+    //  * 5 <= M <= 16: two n-tiles per wave halve the activation re-reads;
+    //  * larger M: more m-tiles per workgroup, capped by registers.
     const ArchInfo &arch = arch_info(current_device());
     const unsigned ntiles = n / kTileN;
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
-    const unsigned want_mt = m <= 16 ? 1 : m <= 32 ? 2 : 4;
+    const int want_mt = m <= 16 ? 1 : m <= 32 ? 2 : 4;
+    const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 0;
+    const int want_nt = m <= 4 ? 1 : 2;
+    const double target_waves = (double)arch.num_cus * 4 * 4;
     const SolutionEntry *best = nullptr;
-    double best_score = -1.0;
+    double best_score = -1e30;
     for (int i = 0; i < fam.count; ++i) {
         const SolutionEntry &e = fam.entries[i];
         if (!entry_fits(e, m, k))
             continue;
         const StreamShape &s = e.shape;
-        if (s.mt != (int)want_mt && !(m > 64 && s.mt == 4))
+        if (s.mt != want_mt)
             continue;
-        if (m <= 4 && s.am == 0)
-            continue; // a staged-activation shape always exists for small M
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
-        const unsigned waves = wgs * s.wn * s.wk;
-        // waves that actually get a span
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
         const double busy = (double)wgs * s.wn * busy_wk;
-        // fill: up to ~8 waves per SIMD keeps enough bytes in flight
-        const double slots = (double)arch.num_cus * 4 * 4;
-        double score = busy < slots ? busy / slots : 1.0;
-        // activation re-reads: prefer more n-tiles per wave as M grows
-        const double a_over_w = (double)(m < 16 ? m : 16) / (4.0 * s.nt);
-        score /= (1.0 + 0.5 * a_over_w);
-        // mild preference for fewer idle waves and deeper rings
-        score *= 1.0 - 0.1 * (1.0 - busy / (double)waves);
-        score *= 1.0 + 0.01 * s.d;
+        double score = 0.0;
+        score -= 4.0 * (s.am != want_am);
+        score -= 1.0 * (s.nt != want_nt);
+        // wave count: under-filling costs more than over-filling
+        score -= busy < target_waves ? 3.0 * (1.0 - busy / target_waves) : 0.25 * (busy / target_waves - 1.0);
+        // spans must divide evenly over the K waves, or some waves idle in the tail
+        const unsigned per = (nspans + s.wk - 1) / s.wk;
+        score -= 2.0 * (1.0 - (double)nspans / ((double)per * s.wk));
+        score += 0.01 * s.d;
         if (score > best_score)
             best_score = score, best = &e;
+    }
+    if (!best) { // relax the m-tile preference
+        for (int i = 0; i < fam.count; ++i)
+            if (entry_fits(fam.entries[i], m, k) && (!best || fam.entries[i].shape.mt > best->shape.mt))
+                best = &fam.entries[i];
     }
     return best;
 }
