@@ -284,9 +284,13 @@ def test_llama70b_shapes_properties(pk, n, k):
         assert np.array_equal(got[i], want)
     a8 = torch.randn((8, k), dtype=torch.bfloat16, device=DEV)
     c8 = pk.mul_nvfp4_a16(a8, b, sp, gsd, 8, n, k, -1)
+    # same kernel for both calls: different solutions split K differently and may round the
+    # f32 sum differently in the last bit, which is legitimate
+    sid = [x for x in pk.get_fp4_solutions(8, n, k, torch.bfloat16, torch.bfloat16) if (x >> 48) & 0xF == 0][0]
+    c8s = pk.mul_nvfp4_a16(a8, b, sp, gsd, 8, n, k, sid)
     for i in (0, 5):
-        c1 = pk.mul_nvfp4_a16(a8[i:i + 1].contiguous(), b, sp, gsd, 1, n, k, -1)
-        assert torch.equal(c1[0], c8[i])
+        c1 = pk.mul_nvfp4_a16(a8[i:i + 1].contiguous(), b, sp, gsd, 1, n, k, sid)
+        assert torch.equal(c1[0], c8s[i])
     rows = rng.integers(0, n, 64)
     dq = O.dequant_nvfp4(q[rows], s[rows])
     _, cf = O.gemm_ref(bits(a8), True, dq, 1.0)

@@ -1,11 +1,10 @@
 mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3) > gpurun_out/r1_tests.log
-timeout 300 python bench.py > gpurun_out/bench_r01.json 2> gpurun_out/bench_r01.err
-timeout 120 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1
-cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bench -o bench -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/prof_bench.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o p -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 100 > $R/gpurun_out/pmc_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 100 > $R/gpurun_out/pmc_write.log 2>&1
-cd $R
-tail -2 gpurun_out/r1_tests.log; cat gpurun_out/bench_r01.json; tail -2 gpurun_out/smoke.log; ls gpurun_out/prof_bench gpurun_out/pmc_fetch
+timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_x1.json 2> gpurun_out/bench_x1.err
+timeout 300 python tools/tune.py --shapes sq8192 --ms 1 --only-default --out gpurun_out/tune_x.json 2>&1 | grep -v amdgpu | tail -2
+timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_x2.json 2> gpurun_out/bench_x2.err
+timeout 300 python tools/dbg_tmp.py 2>&1 | grep rotating
+tail -2 gpurun_out/r1_tests.log; python -c "
+import json
+for f in ('gpurun_out/bench_x1.json','gpurun_out/bench_x2.json'):
+    d=json.load(open(f)); print(f, d['ms_per_step']*1e3, 'us', d['value'])"
