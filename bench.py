@@ -93,6 +93,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rotate-mb", type=int, default=320, help="rotate over at least this many MB of distinct weights")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +110,7 @@ def main() -> None:
     import petit_kernel  # fails loudly when libpetit_amd.so is missing
 
     bytes_per_step = algorithmic_bytes(M, N, K, GROUP)
-    copies = (320 * 1024 * 1024) // bytes_per_step + 2      # > 320 MB of distinct weights
+    copies = (args.rotate_mb * 1024 * 1024) // bytes_per_step + 2   # > 320 MB of distinct weights
     a, gs, qs, ss = make_inputs(1234 + rank, copies)
     a_d = a.to(dev)
     gs_d = gs.to(dev)

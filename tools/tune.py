@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "tune.json"))
     ap.add_argument("--only-default", action="store_true", help="time only the solution_id=-1 choice")
+    ap.add_argument("--rotate-mb", type=int, default=320, help="rotate over at least this many MB of distinct weights")
     args = ap.parse_args()
 
     dev = torch.device("cuda", 0)
@@ -94,7 +95,7 @@ def main():
     for name in args.shapes.split(","):
         n, k = LLAMA70B[name] if name in LLAMA70B else tuple(int(x) for x in name.split("x"))
         wbytes = n * k // 2 + n * k // group
-        copies = max(2, (320 << 20) // wbytes + 2)
+        copies = max(2, (args.rotate_mb << 20) // wbytes + 2)
         gen = torch.Generator(device=dev).manual_seed(1234)
         packed = []
         for _ in range(copies):
