@@ -10,8 +10,8 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     surface petit_kernel.mul_nvfp4_a16(..., solution_id=-1) -> C ABI -> HIP kernel.
     Inputs are synthetic (tests/ops/test_fp4_gemm_quark.py:41-46 distributions, seed 1234),
     resident in HBM before the timed region, and ROTATE over enough distinct (W, scales)
-    copies (> 320 MB) that no launch re-reads weights still sitting in the 256 MB Infinity
-    Cache -- the reference's own benchmark reuses a single buffer
+    copies (default 1.3 GB) that no launch re-reads weights still sitting in the 256 MB
+    Infinity Cache -- the reference's own benchmark reuses a single buffer
     (tools/benchmarks/matmul/rocm/matmul_petit.cc:116-132), which on MI355X would measure the
     cache, not HBM.
 
@@ -89,11 +89,14 @@ def cpu_baseline(a, gs, q, s, budget_s: float = 12.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--rotate-mb", type=int, default=320, help="rotate over at least this many MB of distinct weights")
+    ap.add_argument("--rotate-mb", type=int, default=1280,
+                    help="rotate over at least this many MB of distinct weights; measured on MI355X: per-launch time "
+                         "keeps rising until ~1.3 GB (8.3 us at 40 MB, 8.7 at 320 MB, 9.2 at >= 1.3 GB), i.e. the 256 MB "
+                         "Infinity Cache still serves part of a 320 MB rotation")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,7 +113,7 @@ def main() -> None:
     import petit_kernel  # fails loudly when libpetit_amd.so is missing
 
     bytes_per_step = algorithmic_bytes(M, N, K, GROUP)
-    copies = (args.rotate_mb * 1024 * 1024) // bytes_per_step + 2   # > 320 MB of distinct weights
+    copies = (args.rotate_mb * 1024 * 1024) // bytes_per_step + 2
     a, gs, qs, ss = make_inputs(1234 + rank, copies)
     a_d = a.to(dev)
     gs_d = gs.to(dev)
@@ -130,9 +133,9 @@ def main() -> None:
             dist.barrier()
 
     stream = torch.cuda.Stream(dev)
+    warmup_done = 0
     with torch.cuda.stream(stream):
-        for i in range(args.warmup):               # untimed warm-up steps
-            out = step(i)
+        out = step(0)                              # first call: module load, arch table
         stream.synchronize()
         graph = None
         if not args.no_graph:
@@ -140,12 +143,20 @@ def main() -> None:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=stream):
                     for i in range(args.steps):
-                        out = step(args.warmup + i)
-                graph.replay()                     # one untimed replay (graph upload)
-                stream.synchronize()
+                        out = step(i)
             except Exception as exc:               # capture unsupported: time eager launches
                 print(f"[bench] graph capture failed ({exc}); timing eager launches", file=sys.stderr)
                 graph = None
+        # untimed warm-up: the same steps, so clocks and caches are in steady state
+        if graph is not None:
+            while warmup_done < args.warmup:
+                graph.replay()
+                warmup_done += args.steps
+        else:
+            for i in range(args.warmup):
+                out = step(i)
+            warmup_done = args.warmup
+        stream.synchronize()
 
         # events are recorded on the stream the kernels run on
         e0 = torch.cuda.Event(enable_timing=True)
@@ -158,7 +169,7 @@ def main() -> None:
             graph.replay()                         # exactly args.steps steps
         else:
             for i in range(args.steps):
-                out = step(args.warmup + i)
+                out = step(i)
         e1.record(stream)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
@@ -187,7 +198,7 @@ def main() -> None:
             "unit": "GB/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": warmup_done,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",

@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "tune.json"))
     ap.add_argument("--only-default", action="store_true", help="time only the solution_id=-1 choice")
-    ap.add_argument("--rotate-mb", type=int, default=320, help="rotate over at least this many MB of distinct weights")
+    ap.add_argument("--rotate-mb", type=int, default=1280, help="rotate over at least this many MB of distinct weights")
     args = ap.parse_args()
 
     dev = torch.device("cuda", 0)
