@@ -179,11 +179,10 @@ def main() -> None:
         barrier()
     ev_ms = e0.elapsed_time(e1)
 
-    # whole-job time = slowest rank
-    t = torch.tensor([ev_ms, wall * 1e3], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ev_ms_max, wall_ms_max = t.tolist()
+    # whole-job time = slowest rank (petit_kernel/replicas.py; covered on CPU with gloo)
+    from petit_kernel import replicas
+    ev_ms_max = replicas.max_over_ranks(ev_ms, dev)
+    wall_ms_max = replicas.max_over_ranks(wall * 1e3, dev)
     ms_per_step = ev_ms_max / args.steps
 
     # sanity: the timed kernel really computes the GEMM (checked against the oracle in smoke()/tests)

@@ -50,6 +50,11 @@ bool family_for(int a_type, int b_type, Family *out) {
         out->elem_b = kElemBMxFp4, out->mfma = kMfmaBf16;
         return true;
     }
+    if (a_type == kDataTypeFp16 && mx) { // not in the reference (gemm_fp4_fp16_grid.cc:55-64 rejects it)
+        out->entries = solutions_mx_f16(&out->count);
+        out->elem_b = kElemBMxFp4, out->mfma = kMfmaFp16;
+        return true;
+    }
     return false;
 }
 

@@ -53,10 +53,23 @@ enum : int { kAuxDefault = 0, kAuxNt = 2 };
 struct Bf16 {
     using frag = bf16x8;
     static constexpr int kType = kDataTypeBf16;
+    static constexpr bool kSplit = false;
 };
 struct Fp16 {
     using frag = f16x8;
     static constexpr int kType = kDataTypeFp16;
+    static constexpr bool kSplit = false;
+};
+// fp16 activations against MXFP4 weights (a capability the reference does not have:
+// fp4/warp_schedule_fp16.cuh:22-26 static_asserts it away).  e8m0 block scales span
+// 2^-127..2^127, far outside fp16, so the weights are dequantised to bf16 (exact) and
+// every fp16 activation a is split EXACTLY into two bf16 numbers a = hi + lo
+// (hi = the top 8 significant bits, lo = the remaining <= 3): two bf16 MFMAs per
+// fragment, f32 accumulation, no precision lost anywhere.
+struct Fp16Split {
+    using frag = bf16x8;
+    static constexpr int kType = kDataTypeFp16;
+    static constexpr bool kSplit = true;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
@@ -122,6 +135,23 @@ __device__ __forceinline__ bf16x8 unpack_mx(Bf16, unsigned w, float s) {
     return bf16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
 }
 
+__device__ __forceinline__ bf16x8 unpack_mx(Fp16Split, unsigned w, float s) { return unpack_mx(Bf16{}, w, s); }
+
+// 8 fp16 values -> (hi, lo) bf16 fragments with hi + lo == the fp16 value exactly.
+__device__ __forceinline__ void split_f16(const u32x4 &h, u32x4 &hi, u32x4 &lo) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const f16x2 p = __builtin_bit_cast(f16x2, h[d]);
+        const float f0 = (float)p[0], f1 = (float)p[1];             // exact
+        const unsigned u0 = __builtin_bit_cast(unsigned, f0) & 0xffff0000u;
+        const unsigned u1 = __builtin_bit_cast(unsigned, f1) & 0xffff0000u;
+        const float l0 = f0 - __builtin_bit_cast(float, u0);       // <= 3 significant bits: exact,
+        const float l1 = f1 - __builtin_bit_cast(float, u1);       // and exactly a bf16
+        hi[d] = (u0 >> 16) | u1;
+        lo[d] = (__builtin_bit_cast(unsigned, l0) >> 16) | (__builtin_bit_cast(unsigned, l1) & 0xffff0000u);
+    }
+}
+
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
@@ -142,6 +172,8 @@ __device__ __forceinline__ unsigned pack2(Bf16, float lo, float hi) {
     bf16x2 q = __builtin_convertvector(f32x2{lo, hi}, bf16x2); // RNE, qgemm.cuh:161-176
     return __builtin_bit_cast(unsigned, q);
 }
+__device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi);
+__device__ __forceinline__ unsigned pack2(Fp16Split, float lo, float hi) { return pack2(Fp16{}, lo, hi); }
 __device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi) {
     f16x2 q = __builtin_convertvector(f32x2{lo, hi}, f16x2); // RNE
     return __builtin_bit_cast(unsigned, q);
@@ -219,7 +251,8 @@ struct StreamCfg {
     // one staged activation row: KS tiles x 256 B, padded by one 16-byte slot so
     // that the rows a ds_read_b128 lane group touches fall on different banks
     static constexpr int kARowU4 = KS * 16 + 1;
-    static constexpr int kALdsU4 = AM * kARowU4;                       // per wave
+    static constexpr int kSplitN = AT::kSplit ? 2 : 1;                 // hi / lo images of A
+    static constexpr int kALdsU4 = AM * kARowU4 * kSplitN;             // per wave
     static constexpr int kRedItems = WN * MT * NT * 64;                // float4 outputs per workgroup
     static constexpr int kSmemU4 = WN * WK * kALdsU4 + (WK > 1 ? WK * kRedItems : 0);
     static_assert(KS % D == 0, "ring depth must divide the span");
@@ -325,11 +358,20 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             if constexpr (AM > 0 && (ABL & 1) == 0) {
 #pragma unroll
                 for (int i = 0; i < kAStageLoads; ++i) {
+                    unsigned dst;
                     if constexpr (KS >= 4) {
                         constexpr int kPerRow = KS / 4;
-                        a_lds[(i / kPerRow) * Cfg::kARowU4 + (i % kPerRow) * 64 + lane] = astage[i];
+                        dst = (i / kPerRow) * Cfg::kARowU4 + (i % kPerRow) * 64 + lane;
                     } else {
-                        a_lds[(2 * i + (lane >> 5)) * Cfg::kARowU4 + (lane & 31u)] = astage[i];
+                        dst = (2 * i + (lane >> 5)) * Cfg::kARowU4 + (lane & 31u);
+                    }
+                    if constexpr (AT::kSplit) { // hi image, then lo image AM rows further
+                        u32x4 hi, lo;
+                        split_f16(astage[i], hi, lo);
+                        a_lds[dst] = hi;
+                        a_lds[dst + AM * Cfg::kARowU4] = lo;
+                    } else {
+                        a_lds[dst] = astage[i];
                     }
                 }
             }
@@ -350,6 +392,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxNt);
 
         u32x4 afrag[MT][4];
+        u32x4 afrag_lo[AT::kSplit && AM > 0 ? 4 : 1]; // staged split path: the lo image's fragments
         if constexpr (AM == 0) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -368,6 +411,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     afrag[0][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
                 else
                     afrag[0][j] = a_lds[a_frag_base + j];
+                if constexpr (AT::kSplit)
+                    afrag_lo[j] = a_lds[a_frag_base + AM * Cfg::kARowU4 + j];
             }
         };
         if constexpr (AM > 0) {
@@ -401,13 +446,17 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 // activation fragments: this step's from LDS (staged path), or the next
                 // step's straight from L2 (direct path)
                 u32x4 anext[MT][4];
+                u32x4 anext_lo[AT::kSplit && AM > 0 ? 4 : 1];
                 if constexpr (AM > 0) {
                     // staged path: prefetch the NEXT tile's fragments now, so the LDS
                     // latency hides behind this tile's unpack instead of stalling each MFMA
                     if constexpr (T + 1 < KS) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < 4; ++j) {
                             anext[0][j] = (ABL & 1) ? afrag[0][j] : a_lds[a_frag_base + (T + 1) * 16 + j];
+                            if constexpr (AT::kSplit)
+                                anext_lo[j] = a_lds[a_frag_base + AM * Cfg::kARowU4 + (T + 1) * 16 + j];
+                        }
                         __builtin_amdgcn_sched_barrier(0); // keep the reads at the top of the step
                     }
                 } else if constexpr (kNextA) {
@@ -420,6 +469,15 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                             else
                                 anext[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt + 1) * 256, kAuxDefault);
                         }
+                }
+                // direct path with fp16-split activations: split this step's fragments once
+                u32x4 asplit_hi[AT::kSplit && AM == 0 ? MT : 1][4], asplit_lo[AT::kSplit && AM == 0 ? MT : 1][4];
+                if constexpr (AT::kSplit && AM == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            split_f16(afrag[mt][j], asplit_hi[mt][j], asplit_lo[mt][j]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -442,6 +500,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                             if constexpr (ABL & 4) {
                                 const u32x4 wb = __builtin_bit_cast(u32x4, wf), ab = afrag[mt][j];
                                 a += __builtin_bit_cast(f32x4, wb ^ ab);
+                            } else if constexpr (AT::kSplit && AM > 0) {
+                                a = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(Frag, afrag_lo[j]), a);
+                            } else if constexpr (AT::kSplit) {
+                                a = mfma16(wf, __builtin_bit_cast(Frag, asplit_hi[mt][j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(Frag, asplit_lo[mt][j]), a);
                             } else
                                 a = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), a);
                         }
@@ -458,6 +522,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             afrag[mt][j] = anext[mt][j];
+                    if constexpr (AT::kSplit && AM > 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            afrag_lo[j] = anext_lo[j];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });

@@ -64,5 +64,6 @@ struct SolutionEntry {
 const SolutionEntry *solutions_nv_bf16(int *count);
 const SolutionEntry *solutions_nv_f16(int *count);
 const SolutionEntry *solutions_mx_bf16(int *count);
+const SolutionEntry *solutions_mx_f16(int *count);
 
 } // namespace petit_amd

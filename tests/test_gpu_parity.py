@@ -119,7 +119,8 @@ def test_exhaustive_nv_dequant_bit_exact(pk, golden_dir, is_bf16):
     assert np.array_equal(got.T, want)
 
 
-def test_exhaustive_mx_dequant_bit_exact(pk, golden_dir):
+@pytest.mark.parametrize("is_bf16", [True, False])
+def test_exhaustive_mx_dequant_bit_exact(pk, golden_dir, is_bf16):
     """16 codes x e8m0 1..237 with the reference's row/col-mixing scale generator
     (MxFp4DequantTest, quantization_utils_fp4_test.cc:266-278,311-342)."""
     n, k = 256, 256
@@ -129,10 +130,19 @@ def test_exhaustive_mx_dequant_bit_exact(pk, golden_dir):
     sidx = (np.arange(k // 32)[None, :] + 29 * np.arange(n)[:, None]) % 237
     s = (1 + sidx).astype(np.uint8)
     want = t[code, np.repeat(sidx, 32, axis=1)]
-    a_bits = O.f32_to_bf16_bits(np.eye(k, dtype=np.float32))
-    c = run_case(pk, "mx", a_bits, True, q, s, 1.0, k, n, k)
-    got = to_f32(c, True)
-    assert np.array_equal(got.T, want)
+    eye = np.eye(k, dtype=np.float32)
+    a_bits = O.f32_to_bf16_bits(eye) if is_bf16 else eye.astype(np.float16).view(np.uint16)
+    c = run_case(pk, "mx", a_bits, is_bf16, q, s, 1.0, k, n, k)
+    if is_bf16:
+        assert np.array_equal(to_f32(c, True).T, want)
+    else:
+        # fp16 output: 2^(e-127) leaves the fp16 range for most of 1..237 -- the single f32 -> fp16
+        # rounding (to inf / subnormal / zero) must be the IEEE one, bit for bit
+        with np.errstate(over="ignore"):
+            want16 = want.astype(np.float16)
+        assert np.array_equal(c.view(np.float16).T == 0, want16 == 0)
+        nz = want16 != 0
+        assert np.array_equal(c.T[nz], want16.view(np.uint16)[nz])
 
 
 # --- the reference's pytest cases, from the committed golden vectors ------------------
@@ -151,14 +161,16 @@ def test_nv_golden_cases(pk, golden_dir, name):
                                rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("name", ["mx_64_128_256_1234", "mx_96_96_512_2026"])
+@pytest.mark.parametrize("name", ["mx_64_128_256_1234", "mx_96_96_512_2026",
+                                  "mx_64_128_256_1234_f16", "mx_96_96_512_2026_f16"])
 def test_mx_golden_cases(pk, golden_dir, name):
     g = np.load(golden_dir / f"{name}.npz")
     m, k = g["a"].shape
     n = g["q"].shape[0]
-    c = run_case(pk, "mx", g["a"], True, g["q"], g["s"], float(g["gs"][0]), m, n, k)
-    ref = to_f32(g["c_ref"], True)
-    got = to_f32(c, True)
+    is_bf16 = bool(g["a_is_bf16"])
+    c = run_case(pk, "mx", g["a"], is_bf16, g["q"], g["s"], float(g["gs"][0]), m, n, k)
+    ref = to_f32(g["c_ref"], is_bf16)
+    got = to_f32(c, is_bf16)
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(got), fin)          # overflow to inf in the same places
     assert np.array_equal(np.sign(got[~fin]), np.sign(ref[~fin]))
@@ -206,7 +218,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("m,n,k", SHAPES)
-@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
 def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     if kind == "mx" and n % 32:
         pytest.skip("MX scale tensor contract needs N % 32 (fp4.cc:145-147)")
@@ -216,7 +228,7 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256)])
-@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
 def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
     """The counterpart of the reference's one-gtest-per-tile-shape list
     (fp4/gemm_fp4_fp16_rocm_test.cc:343-381): every enumerated kernel, same inputs."""
