@@ -101,13 +101,11 @@ template <int SEL> __device__ __forceinline__ f16x2 cvt_fp4_f16(unsigned w, floa
 // products are turned into bf16 by TRUNCATION -- one v_perm_b32 per pair picking
 // the two high halves -- instead of v_cvt_pk_bf16_f32, which measures ~10 cycles
 // per wave-instruction on gfx950 against 4 for v_perm_b32 (tools/probes/valu_rate).
-// hipcc/ROCm 7.2 miscompiles __builtin_amdgcn_perm when it can see that both
-// operands are the halves of one 64-bit vector (it emits v_perm_b32 d, x, x); the
-// empty asm hides that relation.  A real asm v_perm would need its own VALU->MFMA
-// wait states, which the compiler only inserts for instructions it can see.
+// NOTE (hipcc / ROCm 7.2): __builtin_bit_cast applied directly to a vector ELEMENT
+// expression (p.y, h[d]) silently reads element 0.  Always copy the element into a
+// scalar first -- every bit_cast in this file takes a named scalar or a whole vector.
 __device__ __forceinline__ unsigned trunc_pack_bf16(f32x2 p) {
-    float x = p.x, y = p.y;
-    asm("" : "+v"(y));
+    const float x = p.x, y = p.y;
     return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y), __builtin_bit_cast(unsigned, x), 0x07060302u);
 }
 __device__ __forceinline__ bf16x8 unpack_nv(Bf16, unsigned w, float s) {
@@ -141,7 +139,8 @@ __device__ __forceinline__ bf16x8 unpack_mx(Fp16Split, unsigned w, float s) { re
 __device__ __forceinline__ void split_f16(const u32x4 &h, u32x4 &hi, u32x4 &lo) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const f16x2 p = __builtin_bit_cast(f16x2, h[d]);
+        const unsigned hd = h[d]; // scalar copy first: see the bit_cast note above
+        const f16x2 p = __builtin_bit_cast(f16x2, hd);
         const float f0 = (float)p[0], f1 = (float)p[1];             // exact
         const unsigned u0 = __builtin_bit_cast(unsigned, f0) & 0xffff0000u;
         const unsigned u1 = __builtin_bit_cast(unsigned, f1) & 0xffff0000u;
