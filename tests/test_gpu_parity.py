@@ -174,8 +174,9 @@ def test_mx_golden_cases(pk, golden_dir, name):
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(got), fin)          # overflow to inf in the same places
     assert np.array_equal(np.sign(got[~fin]), np.sign(ref[~fin]))
-    rel = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30)
-    assert rel.max() <= 1e-2
+    if fin.any():   # e8m0 1..237 against fp16: every output of a case may overflow
+        rel = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-30)
+        assert rel.max() <= 1e-2
 
 
 def test_config1_golden(pk, golden_dir):
