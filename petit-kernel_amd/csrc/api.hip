@@ -63,7 +63,7 @@ bool shape_ok(unsigned n, unsigned k) { return n % kTileN == 0 && k % 256 == 0; 
 // Can this entry run (m, n, k)?  KS has to match the layout K implies, and the
 // staged-activation kernels hold at most AM rows.
 bool entry_fits(const SolutionEntry &e, unsigned m, unsigned k) {
-    return e.shape.ks == span_tiles_for_k(k) && (e.shape.am == 0 || m <= (unsigned)e.shape.am);
+    return e.shape.ks == span_tiles_for_k(k) && (e.shape.am <= 0 || m <= (unsigned)e.shape.am);
 }
 
 // Per-device registered split-K workspace.
@@ -100,6 +100,19 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     const ArchInfo &arch = arch_info(current_device());
     const unsigned ntiles = n / kTileN;
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    if (m >= 48) { // MFMA-bound regime: the tiled kernel, 128-row tiles once M fills them
+        const int want = m >= 96 ? 8 : 4;
+        const SolutionEntry *pick = nullptr;
+        for (int i = 0; i < fam.count; ++i) {
+            const SolutionEntry &e = fam.entries[i];
+            if (e.shape.am != kTiledAm || !entry_fits(e, m, k))
+                continue;
+            if (!pick || (e.shape.mt == want && pick->shape.mt != want))
+                pick = &e;
+        }
+        if (pick)
+            return pick;
+    }
     const int want_mt = m <= 16 ? 1 : m <= 32 ? 2 : 4;
     const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 0;
     const int want_nt = m <= 4 ? 1 : 2;
@@ -111,7 +124,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         if (!entry_fits(e, m, k))
             continue;
         const StreamShape &s = e.shape;
-        if (s.mt != want_mt)
+        if (s.mt != want_mt || s.am == kTiledAm)
             continue;
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
@@ -130,7 +143,8 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     }
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
-            if (entry_fits(fam.entries[i], m, k) && (!best || fam.entries[i].shape.mt > best->shape.mt))
+            if (entry_fits(fam.entries[i], m, k) && fam.entries[i].shape.am != kTiledAm &&
+                (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
     }
     return best;
@@ -321,6 +335,12 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kErrKernelShape;
     }
     const StreamShape &s = e->shape;
+    if (s.am == kTiledAm) {
+        snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d  (wg tile %dx%d, %d threads)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
+                 s.mt, s.nt, s.wn, s.d, 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
+        return kOk;
+    }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",
              a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
              s.mt, s.nt, s.wn, s.wk, s.d, s.am, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,

@@ -1,0 +1,213 @@
+// gemm_tiled.cuh -- the FP4 GEMM for large M (prefill regime, MFMA-bound).
+//
+// Same contract, layout and unpack as gemm_stream.cuh; what changes is the reuse
+// structure.  At M >= ~64 every dequantised weight fragment must feed many MFMAs, and
+// every activation fragment must be shared by many weight tiles:
+//  * a workgroup owns a BM x BN tile of C (BM = 16*MT rows, BN = 16*NTW*WAVES columns)
+//    and walks K in steps of one 128-k weight tile;
+//  * the A tile of a step (BM x 128) is staged in LDS once per workgroup, double
+//    buffered, one barrier per step (the reference's 2-stage LDS pipeline,
+//    gemm_fp4_fp16_grid.cuh:323-431, needs 2-4 barriers per step because W goes
+//    through LDS as well);
+//  * W still never touches LDS: each wave streams the tiles of its own NTW n-tiles
+//    straight into VGPRs (ring of D), unpacks each word ONCE (hardware convert) and
+//    reuses the fragment across all MT m-tiles: 4*MT*NTW MFMAs per step against
+//    NTW*4 unpacks, so the VALU work hides in the MFMA shadow;
+//  * C^T = W . A^T as in the streaming kernel: a lane ends with 4 consecutive n of one
+//    m, 8-byte stores.
+// One workgroup per CU at 1 wave per SIMD is the intended residency (the kernel uses
+// ~200 VGPRs on purpose: accumulators for a 128 x 32 slab per wave).
+#pragma once
+
+#include "gemm_stream.cuh"
+
+namespace petit_amd {
+
+//   MT   m-tiles (of 16) per workgroup = per wave          (BM = 16*MT)
+//   NTW  n-tiles (of 16) per wave                          (BN = 16*NTW*WAVES)
+//   WAVES waves per workgroup (along N)
+//   D    W ring depth in k-tiles
+template <class AT_, int FMT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct TiledCfg {
+    using AT = AT_;
+    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NTW = NTW_, WAVES = WAVES_, D = D_;
+    static constexpr int kThreads = 64 * WAVES;
+    static constexpr int BM = 16 * MT;
+    static constexpr int kRowU4 = 17;                     // 16 units of 16 B + 1 pad (bank spread)
+    static constexpr int kBufU4 = BM * kRowU4;            // one A tile image
+    static constexpr int kUnitsPerThread = BM * 16 / kThreads;
+    static_assert(KS % D == 0, "ring depth must divide the span");
+    static_assert((BM * 16) % kThreads == 0, "A tile must split evenly over the workgroup");
+    static_assert(2 * kBufU4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(!AT::kSplit, "fp16 x MXFP4 is served by the streaming kernel only");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArgs p) {
+    using AT = typename Cfg::AT;
+    using Frag = typename AT::frag;
+    constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
+    constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
+    constexpr unsigned kOob = 0x80000000u;
+    constexpr int UPT = Cfg::kUnitsPerThread;
+
+    __shared__ u32x4 smem[2 * Cfg::kBufU4];
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned r = lane & 15u, g = lane >> 4;
+
+    const unsigned ktiles = p.k / kTileK;
+    const unsigned nspans = ktiles / KS;
+    const unsigned ntiles = p.n / kTileN;
+    const unsigned nt0 = (blockIdx.x * WAVES + wave) * NTW;
+    const unsigned m0 = blockIdx.y * Cfg::BM;
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)NTW, ntiles - nt0) : 0u;
+    const unsigned w_row_bytes = ktiles * kTileBytes;
+    const unsigned s_row_bytes = (FMT == kFmtNv) ? p.k : p.k / 2;
+    const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
+
+    // a wave whose n-tiles all fall beyond N still helps staging A and hits the barriers
+    const unsigned nt_base = valid_nt ? nt0 : 0u;
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        make_rsrc((const char *)p.w + (size_t)nt_base * w_row_bytes, valid_nt * w_row_bytes);
+    const __amdgpu_buffer_rsrc_t s_rsrc =
+        make_rsrc((const char *)p.s + (size_t)nt_base * s_row_bytes, valid_nt * s_row_bytes);
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc((const char *)p.a + (size_t)m0 * p.k * 2, rows * p.k * 2);
+
+    unsigned w_voff[NTW], s_voff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + nt * w_row_bytes : kOob;
+        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + nt * s_row_bytes : kOob;
+    }
+    // A staging: unit u = tid + i*kThreads -> row u/16, 16-byte column u%16 (a row's 256 B are
+    // read by 16 consecutive lanes: full lines)
+    unsigned a_g_voff[UPT], a_l_idx[UPT];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        const unsigned u = tid + i * Cfg::kThreads, row = u >> 4, col = u & 15u;
+        a_g_voff[i] = row * p.k * 2 + col * 16; // rows >= M fall out of range -> zeros
+        a_l_idx[i] = row * Cfg::kRowU4 + col;
+    }
+    const unsigned a_frag_base = r * Cfg::kRowU4 + g * 4; // + mt*16*kRowU4 + j
+
+    // --- prologue
+    u32x4 astage[UPT];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i)
+        astage[i] = buf_load16(a_rsrc, a_g_voff[i], 0u, kAuxDefault);
+    ScaleRec<FMT, KS> srec[NTW], srec_next[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+        srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], 0u);
+    u32x4 wring[D][NTW];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], i * kTileBytes, kAuxDefault);
+#pragma unroll
+    for (int i = 0; i < UPT; ++i)
+        smem[a_l_idx[i]] = astage[i];
+    __syncthreads();
+
+    auto span_body = [&](const unsigned sp, auto last_c) {
+        constexpr bool kLast = decltype(last_c)::value;
+        const unsigned kt0 = sp * KS;
+        if constexpr (!kLast) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                srec_next[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], (sp + 1) * 64 * kRecBytes);
+        }
+        static_for<0, KS>([&](auto t_c) {
+            constexpr int T = decltype(t_c)::value;
+            constexpr int SLOT = T % D;
+            constexpr bool kRefill = !kLast || (T + D < KS);
+            constexpr bool kNextA = !kLast || (T + 1 < KS);
+            const unsigned kt = kt0 + T;
+            const u32x4 *const a_cur = smem + ((kt & 1u) ? Cfg::kBufU4 : 0);
+            u32x4 *const a_nxt = smem + ((kt & 1u) ? 0 : Cfg::kBufU4);
+            // next step's A tile: global -> registers now, LDS after this step's reads
+            if constexpr (kNextA) {
+#pragma unroll
+                for (int i = 0; i < UPT; ++i)
+                    astage[i] = buf_load16(a_rsrc, a_g_voff[i], (kt + 1) * 256, kAuxDefault);
+            }
+            // unpack this step's weight words once
+            Frag wf[NTW][4];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                float s_lo, s_hi;
+                tile_scales<FMT, KS, T>(srec[nt], s_lo, s_hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned w = wring[SLOT][nt][j];
+                    if constexpr (FMT == kFmtNv)
+                        wf[nt][j] = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
+                    else
+                        wf[nt][j] = unpack_mx(AT{}, w, s_lo);
+                }
+            }
+            if constexpr (kRefill) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxDefault);
+            }
+            // every m-tile: 4 fragments from LDS, 4*NTW MFMAs
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                u32x4 af[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    af[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) // j outer: consecutive MFMAs hit different accumulators
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[mt][nt] = mfma16(wf[nt][j], __builtin_bit_cast(Frag, af[j]), acc[mt][nt]);
+            }
+            if constexpr (kNextA) {
+#pragma unroll
+                for (int i = 0; i < UPT; ++i)
+                    a_nxt[a_l_idx[i]] = astage[i];
+                __syncthreads();
+            }
+        });
+        if constexpr (!kLast) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                srec[nt] = srec_next[nt];
+        }
+    };
+    for (unsigned sp = 0; sp + 1 < nspans; ++sp)
+        span_body(sp, std::false_type{});
+    span_body(nspans - 1, std::true_type{});
+
+    // --- epilogue: x global scale, one RNE rounding, 8-byte stores
+    const float gs = *p.gs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const unsigned m = m0 + mt * 16 + r;
+            const unsigned n = (nt0 + nt) * 16 + g * 4;
+            if (m < p.m && (unsigned)nt < valid_nt) {
+                const f32x4 v = acc[mt][nt];
+                uint2 o;
+                o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
+                o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
+                *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = o;
+            }
+        }
+}
+
+} // namespace petit_amd

@@ -18,7 +18,10 @@
 //   bits 48-51  warp_partition    the reference's NK(0)/Cooperative(1) enum, never 1 in
 //                                 its shipped table; here: activation path,
 //                                 0 = direct L2 fragments, 1/2/3 = 1/2/4 rows staged
-//                                 through wave-private LDS (AM in gemm_stream.cuh)
+//                                 through wave-private LDS (AM in gemm_stream.cuh);
+//                                 8 = the tiled large-M kernel (gemm_tiled.cuh), whose
+//                                 fields read: tile_m = MT, warp_partition_n = WAVES,
+//                                 bits 52-55 = NTW, warp_partition_k = 1
 //   bits 52-55  [was padding]     NT  n-tiles per wave
 //   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
 //   bits 60-63  [was padding]     split-K across workgroups (gridDim.z), >= 1
@@ -36,9 +39,10 @@ enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u };
 enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u };
 
 struct StreamShape {
-    int ks, mt, nt, wn, wk, d, am;
+    int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel
 };
-constexpr unsigned am_code(int am) { return am == 0 ? 0u : am == 1 ? 1u : am == 2 ? 2u : 3u; }
+constexpr int kTiledAm = -1;
+constexpr unsigned am_code(int am) { return am == kTiledAm ? 8u : am == 0 ? 0u : am == 1 ? 1u : am == 2 ? 2u : 3u; }
 
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {
     return (uint64_t)(s.mt & 0xff) | ((uint64_t)((s.wn * s.nt) & 0xff) << 8) |
