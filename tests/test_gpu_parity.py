@@ -215,6 +215,7 @@ SHAPES = [
     # (m, n, k): ragged M, N % 16 only, every span size (K % 1024 / 512 / 256)
     (1, 16, 256), (1, 64, 1024), (3, 48, 512), (7, 80, 768), (16, 128, 2048), (17, 64, 1024),
     (33, 96, 1024), (64, 64, 2048), (100, 32, 256), (5, 4096, 4096), (130, 256, 1024),
+    (512, 1024, 2048), (257, 144, 768),      # the tiled large-M kernel, ragged M and N
 ]
 
 

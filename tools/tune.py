@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "tune.json"))
     ap.add_argument("--only-default", action="store_true", help="time only the solution_id=-1 choice")
+    ap.add_argument("--compare-dense", action="store_true",
+                    help="also time torch.matmul (hipBLASLt/rocBLAS) on a dense 16-bit weight of the same shape")
     ap.add_argument("--rotate-mb", type=int, default=1280, help="rotate over at least this many MB of distinct weights")
     args = ap.parse_args()
 
@@ -145,16 +147,32 @@ def main():
                 results.append({"solution": f"0x{sid:x}", "desc": _lib.describe_solution(sid), "us_median": us_med,
                                 "us_min": min(us), "gbs": nbytes / us_med / 1e3, "frac_hbm": nbytes / us_med / 1e3 / HBM_PEAK,
                                 "tflops": 2.0 * m * n * k / us_med / 1e6, "is_default": sid == default_sid})
+            dense = None
+            if args.compare_dense:
+                # the reference's comparator (tools/benchmarks/matmul/rocm/matmul_hipblaslt.cc): a plain
+                # 16-bit GEMM C = A . Wd^T through the vendor library, weights rotated the same way
+                dcopies = max(2, min(copies, (args.rotate_mb << 20) // (n * k * 2) + 2))
+                wd = [torch.randn((n, k), device=dev, dtype=torch.float32).to(dtype) for _ in range(dcopies)]
+                def dlaunch(i):
+                    torch.matmul(a, wd[i % dcopies].t(), out=c)
+                us = time_graph(dlaunch, max(10, launches // 4), args.reps, stream)
+                us_med = sorted(us)[len(us) // 2]
+                dense = {"us_median": us_med, "tflops": 2.0 * m * n * k / us_med / 1e6,
+                         "gbs_dense_weights": (2.0 * n * k + 2 * m * k + 2 * m * n) / us_med / 1e3}
+                del wd
             ok = sorted([r for r in results if "us_median" in r], key=lambda r: r["us_median"])
             entry = {"shape": name, "n": n, "k": k, "m": m, "bytes": nbytes, "ideal_us_at_8TBs": ideal_us,
-                     "copies": copies, "launches": launches, "results": ok + [r for r in results if "error" in r]}
+                     "copies": copies, "launches": launches, "dense_16bit_gemm": dense,
+                     "results": ok + [r for r in results if "error" in r]}
             report["results"].append(entry)
             if ok:
                 best = ok[0]
                 dflt = next((r for r in ok if r["is_default"]), None)
                 print(f"{name:8s} M={m:<3d} best {best['us_median']:8.2f} us {best['gbs']:7.0f} GB/s "
                       f"({100 * best['frac_hbm']:.1f}% of 8 TB/s) {best['desc']}"
-                      + (f" | default {dflt['us_median']:.2f} us" if dflt else ""), flush=True)
+                      + (f" | default {dflt['us_median']:.2f} us" if dflt else "")
+                      + (f" | {best['tflops']:.0f} TF vs dense 16-bit GEMM {dense['us_median']:.1f} us {dense['tflops']:.0f} TF" if dense else ""),
+                      flush=True)
                 rows.append((a_type, b_type, n, k, m, int(best["solution"], 16)))
         del packed
         torch.cuda.empty_cache()
