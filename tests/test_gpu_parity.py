@@ -42,12 +42,17 @@ def to_f32(b: np.ndarray, is_bf16: bool) -> np.ndarray:
     return O.bf16_bits_to_f32(b) if is_bf16 else O.f16_bits_to_f32(b)
 
 
-def check_gemm(c_bits, ref_f32, is_bf16):
+def check_gemm(c_bits, ref_f32, is_bf16, sum_abs=None):
+    """sum_abs: optional sum_k |a||w| per output.  With e8m0 block scales the products span many
+    binades, and ANY f32-accumulating implementation carries ~sqrt(K)*2^-24 of that sum as absolute
+    error; where the true result cancels to ~0 that, not 1e-2, is the honest bound."""
     c = to_f32(c_bits, is_bf16).astype(np.float64)
     ref = ref_f32.astype(np.float64)
     fin = np.isfinite(ref) & (np.abs(ref) < (3.0e38 if is_bf16 else 6.0e4))
     err = np.abs(c - ref)
     bound = np.maximum(1e-2, 1e-2 * np.abs(ref))
+    if sum_abs is not None:
+        bound = np.maximum(bound, 1e-5 * sum_abs)
     assert np.isfinite(c[fin]).all()
     assert (err[fin] <= bound[fin]).all(), f"max err {err[fin].max()} at ref {ref[fin][err[fin].argmax()]}"
     # and much tighter on average: one 16-bit rounding of an f32-accumulated sum
@@ -211,6 +216,14 @@ def oracle_ref(kind, a_bits, is_bf16, q, s, gs):
     return cf
 
 
+def oracle_sum_abs(kind, a_bits, is_bf16, q, s, gs):
+    if kind != "mx":
+        return None
+    dq = np.abs(O.dequant_mxfp4(q, s))
+    a = np.abs(to_f32(a_bits, is_bf16))
+    return (a @ dq.T) * gs
+
+
 SHAPES = [
     # (m, n, k): ragged M, N % 16 only, every span size (K % 1024 / 512 / 256)
     (1, 16, 256), (1, 64, 1024), (3, 48, 512), (7, 80, 768), (16, 128, 2048), (17, 64, 1024),
@@ -226,7 +239,7 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
         pytest.skip("MX scale tensor contract needs N % 32 (fp4.cc:145-147)")
     a, q, s, gs = random_problem(kind, m, n, k, 1000 + m + n + k, is_bf16)
     c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k)
-    check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16)
+    check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256)])
@@ -238,6 +251,7 @@ def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
         pytest.skip("MX scale tensor contract needs N % 32")
     a, q, s, gs = random_problem(kind, m, n, k, 77 + m + n + k, is_bf16)
     ref = oracle_ref(kind, a, is_bf16, q, s, gs)
+    sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
     h = pk.PetitSolutionHints()
     h.a_type = torch.bfloat16 if is_bf16 else torch.float16
     h.c_type = h.a_type
@@ -246,7 +260,7 @@ def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
     assert sols
     for sid in sols:
         c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid)
-        check_gemm(c, ref, is_bf16)
+        check_gemm(c, ref, is_bf16, sum_abs)
 
 
 def test_unknown_solution_and_bad_shapes_raise(pk):
