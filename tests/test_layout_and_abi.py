@@ -103,7 +103,7 @@ def test_solution_enumeration_and_ids():
     for s in sols:
         assert (s >> 28) & 0xF == 1 and (s >> 32) & 0xF == 1  # element_b NvFp4, mfma bf16 (gemm.h:14-24)
         assert (s >> 24) & 0xF == 3                           # Grid | HighPrecision (gemm.h:8-12)
-        assert "stream bf16xnvfp4" in _lib.describe_solution(s)
+        assert "bf16xnvfp4" in _lib.describe_solution(s)  # "stream ..." or "tiled ..."
     # both call shapes of the reference
     h = petit_kernel.PetitSolutionHints()
     h.a_type = petit_kernel.DataType.float16
