@@ -63,7 +63,7 @@ bool shape_ok(unsigned n, unsigned k) { return n % kTileN == 0 && k % 256 == 0; 
 // Can this entry run (m, n, k)?  KS has to match the layout K implies, and the
 // staged-activation kernels hold at most AM rows.
 bool entry_fits(const SolutionEntry &e, unsigned m, unsigned k) {
-    return e.shape.ks == span_tiles_for_k(k) && (e.shape.am <= 0 || m <= (unsigned)e.shape.am);
+    return e.shape.ks == span_tiles_for_k(k) && (e.shape.am <= 0 || m <= (unsigned)am_rows(e.shape.am));
 }
 
 // Per-device registered split-K workspace.
@@ -130,7 +130,8 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
         const double busy = (double)wgs * s.wn * busy_wk;
         double score = 0.0;
-        score -= 4.0 * (s.am != want_am);
+        score -= 4.0 * (am_rows(s.am) != want_am);
+        score += 0.5 * (s.am >= kBfpAm); // bf16 x NVFP4, M <= 4: the fp16 pipeline unpacks cheaper
         score -= 1.0 * (s.nt != want_nt);
         // wave count: under-filling costs more than over-filling
         score -= busy < target_waves ? 3.0 * (1.0 - busy / target_waves) : 0.25 * (busy / target_waves - 1.0);
@@ -343,8 +344,10 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",
              a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
-             s.mt, s.nt, s.wn, s.wk, s.d, s.am, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
+             s.mt, s.nt, s.wn, s.wk, s.d, am_rows(s.am), solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
              64 * s.wn * s.wk);
+    if (s.am >= kBfpAm)
+        strncat(buf, " bfp16", len - strlen(buf) - 1);
     return kOk;
 }
 

@@ -2,4 +2,5 @@
 #define PETIT_TU_AT Bf16
 #define PETIT_TU_FMT kFmtNv
 #define PETIT_TU_TABLE solutions_nv_bf16
+#define PETIT_TU_BFP_AT Bf16Bfp
 #include "stream_tu.inc"

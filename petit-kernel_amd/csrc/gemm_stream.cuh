@@ -53,12 +53,28 @@ enum : int { kAuxDefault = 0, kAuxNt = 2 };
 struct Bf16 {
     using frag = bf16x8;
     static constexpr int kType = kDataTypeBf16;
-    static constexpr bool kSplit = false;
+    static constexpr bool kSplit = false, kBfp = false;
 };
 struct Fp16 {
     using frag = f16x8;
     static constexpr int kType = kDataTypeFp16;
-    static constexpr bool kSplit = false;
+    static constexpr bool kSplit = false, kBfp = false;
+};
+// bf16 activations on the fp16 pipeline (staged path only).  The fp16 unpack of an
+// NVFP4 word is 8 VALU (convert + v_pk_mul_f16) against 12 for bf16 (convert to f32,
+// v_pk_mul_f32, v_perm_b32), and the unpack is what the small-M kernel is exposed on.
+// bf16 has 8 significant bits, fp16 has 11, so a bf16 value is exactly an fp16 value
+// whenever its exponent fits.  Each wave therefore rescales ITS span of every
+// activation row by a power of two (block floating point: 2^-sh with sh chosen from
+// the span's largest exponent so the maximum lands in [2^14, 2^15)), converts to
+// fp16, accumulates that span in f32 and multiplies the span's partial sum back by
+// 2^sh before it joins the running total.  Exact except for elements more than 2^29
+// below their span's maximum (fp16 subnormal range), whose contribution to the sum is
+// below 2^-29 of the largest term -- far under the single bf16 rounding of the result.
+struct Bf16Bfp {
+    using frag = f16x8;
+    static constexpr int kType = kDataTypeBf16;
+    static constexpr bool kSplit = false, kBfp = true;
 };
 // fp16 activations against MXFP4 weights (a capability the reference does not have:
 // fp4/warp_schedule_fp16.cuh:22-26 static_asserts it away).  e8m0 block scales span
@@ -69,7 +85,7 @@ struct Fp16 {
 struct Fp16Split {
     using frag = bf16x8;
     static constexpr int kType = kDataTypeFp16;
-    static constexpr bool kSplit = true;
+    static constexpr bool kSplit = true, kBfp = false;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
@@ -124,6 +140,8 @@ __device__ __forceinline__ f16x8 unpack_nv(Fp16, unsigned w, float s) {
     f16x2 q3 = cvt_fp4_f16<3>(w, 1.0f) * s2;
     return f16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
 }
+__device__ __forceinline__ f16x8 unpack_nv(Fp16, unsigned w, float s);
+__device__ __forceinline__ f16x8 unpack_nv(Bf16Bfp, unsigned w, float s) { return unpack_nv(Fp16{}, w, s); }
 // MXFP4 -> bf16: the e8m0 block scale (a power of two) rides in the convert.
 __device__ __forceinline__ bf16x8 unpack_mx(Bf16, unsigned w, float s) {
     bf16x2 q0 = cvt_fp4_bf16<0>(w, s);
@@ -171,6 +189,7 @@ __device__ __forceinline__ unsigned pack2(Bf16, float lo, float hi) {
     bf16x2 q = __builtin_convertvector(f32x2{lo, hi}, bf16x2); // RNE, qgemm.cuh:161-176
     return __builtin_bit_cast(unsigned, q);
 }
+__device__ __forceinline__ unsigned pack2(Bf16Bfp, float lo, float hi) { return pack2(Bf16{}, lo, hi); }
 __device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi);
 __device__ __forceinline__ unsigned pack2(Fp16Split, float lo, float hi) { return pack2(Fp16{}, lo, hi); }
 __device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi) {
@@ -258,6 +277,7 @@ struct StreamCfg {
     static_assert(kThreads <= 1024, "workgroup too large");
     static_assert(AM == 0 || (MT == 1 && (AM == 1 || AM == 2 || AM == 4)), "staged path: MT == 1, AM in {1,2,4}");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(!AT::kBfp || (AM > 0 && KS >= 4 && FMT == 0), "block-floating-point A: staged NVFP4 path only");
 };
 
 template <class Cfg>
@@ -303,6 +323,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
             for (int q = 0; q < NACC; ++q)
                 acc[mt][nt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // block-floating-point path: acc holds ONE span's partial sums, total the running sum
+    f32x4 total[AT::kBfp ? NT : 1];
+#pragma unroll
+    for (int nt = 0; nt < (AT::kBfp ? NT : 1); ++nt)
+        total[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if ((ABL & 8) == 0 && nt0 < ntiles && sp_begin < sp_end) {
         const unsigned valid_nt = min((unsigned)NT, ntiles - nt0);
@@ -353,8 +379,47 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 }
             }
         };
+        float bfp_up = 1.0f; // 2^sh of this lane's activation row for the span now in LDS
         auto write_a_stage = [&]() {
             if constexpr (AM > 0 && (ABL & 1) == 0) {
+                if constexpr (AT::kBfp) {
+                    constexpr int kPerRow = KS / 4;
+                    float up_row[AM];
+#pragma unroll
+                    for (int rr = 0; rr < AM; ++rr) {
+                        // largest |bf16| bit pattern of the row's span: per lane, then across the wave
+                        unsigned mx = 0;
+#pragma unroll
+                        for (int q = 0; q < kPerRow; ++q)
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const unsigned v = astage[rr * kPerRow + q][d] & 0x7fff7fffu;
+                                mx = max(mx, max(v & 0xffffu, v >> 16));
+                            }
+#pragma unroll
+                        for (int off = 32; off >= 1; off >>= 1)
+                            mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+                        int sh = (int)(mx >> 7) - 141; // biased exponent - 127 - 14
+                        sh = mx == 0 ? 0 : min(max(sh, -126), 126);
+                        const float dn = __builtin_bit_cast(float, (unsigned)(127 - sh) << 23);
+                        up_row[rr] = __builtin_bit_cast(float, (unsigned)(127 + sh) << 23);
+#pragma unroll
+                        for (int q = 0; q < kPerRow; ++q)
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const unsigned v = astage[rr * kPerRow + q][d];
+                                const unsigned lo_bits = v << 16, hi_bits = v & 0xffff0000u;
+                                const float lo = __builtin_bit_cast(float, lo_bits) * dn;
+                                const float hi = __builtin_bit_cast(float, hi_bits) * dn;
+                                const auto h2 = __builtin_amdgcn_cvt_pkrtz(lo, hi); // exact when in range
+                                astage[rr * kPerRow + q][d] = __builtin_bit_cast(unsigned, h2);
+                            }
+                    }
+                    bfp_up = up_row[0];
+#pragma unroll
+                    for (int rr = 1; rr < AM; ++rr)
+                        bfp_up = (r == (unsigned)rr) ? up_row[rr] : bfp_up;
+                }
 #pragma unroll
                 for (int i = 0; i < kAStageLoads; ++i) {
                     unsigned dst;
@@ -529,6 +594,16 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (AT::kBfp) { // fold this span: total += 2^sh * (span partial sums)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int q = 0; q < NACC; ++q) {
+                        total[nt] += acc[0][nt][q] * bfp_up;
+                        acc[0][nt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            }
             if constexpr (!kLast) {
                 // every fragment of this span has been read (LDS is in order within a
                 // wave): the slice can take the next span's activations
@@ -573,9 +648,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            accs[mt][nt] = acc[mt][nt][0];
-            if constexpr (NACC == 2)
-                accs[mt][nt] += acc[mt][nt][1];
+            if constexpr (AT::kBfp) {
+                accs[mt][nt] = total[nt];
+            } else {
+                accs[mt][nt] = acc[mt][nt][0];
+                if constexpr (NACC == 2)
+                    accs[mt][nt] += acc[mt][nt][1];
+            }
         }
     if constexpr (WK == 1) {
 #pragma unroll

@@ -19,6 +19,8 @@
 //                                 its shipped table; here: activation path,
 //                                 0 = direct L2 fragments, 1/2/3 = 1/2/4 rows staged
 //                                 through wave-private LDS (AM in gemm_stream.cuh);
+//                                 5/6/7 = the same staged paths on the fp16 pipeline
+//                                 with block-floating-point activations (bf16 x NVFP4),
 //                                 8 = the tiled large-M kernel (gemm_tiled.cuh), whose
 //                                 fields read: tile_m = MT, warp_partition_n = WAVES,
 //                                 bits 52-55 = NTW, warp_partition_k = 1
@@ -42,7 +44,13 @@ struct StreamShape {
     int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel
 };
 constexpr int kTiledAm = -1;
-constexpr unsigned am_code(int am) { return am == kTiledAm ? 8u : am == 0 ? 0u : am == 1 ? 1u : am == 2 ? 2u : 3u; }
+// am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
+// per-span block floating point (Bf16Bfp in gemm_stream.cuh); codes 5 / 6 / 7
+constexpr int kBfpAm = 100;
+constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
+constexpr unsigned am_code(int am) {
+    return am == kTiledAm ? 8u : am == 0 ? 0u : (am_rows(am) == 1 ? 1u : am_rows(am) == 2 ? 2u : 3u) + (am >= kBfpAm ? 4u : 0u);
+}
 
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {
     return (uint64_t)(s.mt & 0xff) | ((uint64_t)((s.wn * s.nt) & 0xff) << 8) |
