@@ -189,6 +189,15 @@ def main() -> None:
     assert out.shape == (M, N) and torch.isfinite(out.float()).all()
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes of the same command (tools/collect_profiles.sh,
+        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); rocprofv3 cannot run inside this process
+        traffic = None
+        for cand in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+            try:
+                traffic = json.loads(cand.read_text())["traffic_bytes_per_launch"]
+                break
+            except Exception:
+                pass
         per_gpu_gbs = bytes_per_step / (ms_per_step * 1e-3) / 1e9
         from petit_kernel import _lib
         import ctypes as C
@@ -219,7 +228,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": per_gpu_gbs / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "kernel": "petit_amd::gemm_stream_kernel",
                 "bytes_per_launch": bytes_per_step,
                 "us_per_launch": ms_per_step * 1e3,
