@@ -348,6 +348,11 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
              64 * s.wn * s.wk);
     if (s.am >= kBfpAm)
         strncat(buf, " bfp16", len - strlen(buf) - 1);
+    if (s.pa > 1) {
+        char t[16];
+        snprintf(t, sizeof(t), " pa%d", s.pa);
+        strncat(buf, t, len - strlen(buf) - 1);
+    }
     return kOk;
 }
 

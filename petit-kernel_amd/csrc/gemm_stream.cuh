@@ -261,10 +261,14 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 //         3 us of a 12 us launch (TA issue-bound), see DESIGN.md.
 //   ABL   ablation bits for tools/ablate (0 in every shipped kernel):
 //         1 no activation loads, 2 no unpack, 4 no MFMA, 8 empty kernel
-template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_, int AM_ = 0, int ABL_ = 0>
+//   PA    direct path (AM == 0) only: how many tiles ahead the activation fragments are
+//         requested from L2 (ring of PA fragment sets; PA divides KS)
+template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_, int AM_ = 0, int ABL_ = 0, int PA_ = 1>
 struct StreamCfg {
     using AT = AT_;
     static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_, AM = AM_, ABL = ABL_;
+    static constexpr int PA = PA_;
+    static_assert(KS % PA_ == 0 && PA_ >= 1, "activation prefetch distance must divide the span");
     static constexpr int kThreads = 64 * WN * WK;
     // one staged activation row: KS tiles x 256 B, padded by one 16-byte slot so
     // that the rows a ds_read_b128 lane group touches fall on different banks
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
     using AT = typename Cfg::AT;
     using Frag = typename AT::frag;
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT;
-    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, AM = Cfg::AM, ABL = Cfg::ABL;
+    constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, AM = Cfg::AM, ABL = Cfg::ABL, PA = Cfg::PA;
     constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
     // A voffset this large is out of range for every descriptor built below
     // whatever the generation's rule for soffset is (masked loads use soffset 0).
@@ -457,16 +461,20 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 
         u32x4 afrag[MT][4];
         u32x4 afrag_lo[AT::kSplit && AM > 0 ? 4 : 1]; // staged split path: the lo image's fragments
+        // direct path: ring of PA fragment sets, slot T % PA holds tile T of the span
+        u32x4 aring[AM == 0 ? PA : 1][MT][4];
         if constexpr (AM == 0) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int i = 0; i < PA; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (ABL & 1)
-                        afrag[mt][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
-                    else
-                        afrag[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt_begin * 256, kAuxDefault);
-                }
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (ABL & 1)
+                            aring[i][mt][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
+                        else
+                            aring[i][mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt_begin + i) * 256, kAuxDefault);
+                    }
         }
         auto load_first_frags = [&]() { // fragments of tile 0 of the span now in LDS
 #pragma unroll
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 constexpr int T = decltype(t_c)::value;
                 constexpr int SLOT = T % D;
                 constexpr bool kRefill = !kLast || (T + D < KS);
-                constexpr bool kNextA = !kLast || (T + 1 < KS);
+                constexpr bool kNextA = !kLast || (T + PA < KS); // direct path: refill the ring slot
                 const unsigned kt = kt0 + T;
                 // activation fragments: this step's from LDS (staged path), or the next
                 // step's straight from L2 (direct path)
@@ -523,16 +531,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                         }
                         __builtin_amdgcn_sched_barrier(0); // keep the reads at the top of the step
                     }
-                } else if constexpr (kNextA) {
+                } else {
+                    // direct path: this tile's fragments come out of ring slot T % PA
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if constexpr (ABL & 1)
-                                anext[mt][j] = afrag[mt][j];
-                            else
-                                anext[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt + 1) * 256, kAuxDefault);
-                        }
+                        for (int j = 0; j < 4; ++j)
+                            afrag[mt][j] = aring[T % PA][mt][j];
                 }
                 // direct path with fp16-split activations: split this step's fragments once
                 u32x4 asplit_hi[AT::kSplit && AM == 0 ? MT : 1][4], asplit_lo[AT::kSplit && AM == 0 ? MT : 1][4];
@@ -580,13 +585,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     for (int nt = 0; nt < NT; ++nt)
                         wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxNt);
                 }
-                if constexpr ((AM == 0 && kNextA) || (AM > 0 && T + 1 < KS)) {
+                if constexpr (AM == 0 && kNextA && (ABL & 1) == 0) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            afrag[mt][j] = anext[mt][j];
-                    if constexpr (AT::kSplit && AM > 0) {
+                            aring[T % PA][mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt + PA) * 256, kAuxDefault);
+                }
+                if constexpr (AM > 0 && T + 1 < KS) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        afrag[0][j] = anext[0][j];
+                    if constexpr (AT::kSplit) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             afrag_lo[j] = anext_lo[j];

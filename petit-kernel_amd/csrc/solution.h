@@ -7,7 +7,9 @@
 //
 //   bits  0- 7  tile_m            m-tiles (of 16) per workgroup        = MT
 //   bits  8-15  tile_n            n-tiles (of 16) per workgroup        = WN*NT
-//   bits 16-23  tile_k            k per span in units of 64            = 2*KS
+//   bits 16-23  tile_k            k per span in units of 64            = 2*KS (low 5 bits);
+//                                 bits 21-23: log2 of the direct-path activation
+//                                 prefetch distance PA
 //   bits 24-27  features          Grid (1) | HighPrecision (2)  -- always 3 here:
 //                                 every gfx950 kernel dequantises exactly
 //   bits 28-31  element_b         1 NVFP4, 2 MXFP4          (MatmulElementB)
@@ -42,7 +44,9 @@ enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u };
 
 struct StreamShape {
     int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel
+    int pa = 1;                    // direct-path activation prefetch distance (1, 2, 4 or 8 tiles)
 };
+constexpr unsigned pa_code(int pa) { return pa == 8 ? 3u : pa == 4 ? 2u : pa == 2 ? 1u : 0u; }
 constexpr int kTiledAm = -1;
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
 // per-span block floating point (Bf16Bfp in gemm_stream.cuh); codes 5 / 6 / 7
@@ -54,7 +58,7 @@ constexpr unsigned am_code(int am) {
 
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {
     return (uint64_t)(s.mt & 0xff) | ((uint64_t)((s.wn * s.nt) & 0xff) << 8) |
-           ((uint64_t)((2 * s.ks) & 0xff) << 16) | ((uint64_t)(kFeatGrid | kFeatHighPrecision) << 24) |
+           ((uint64_t)(((2 * s.ks) & 0x1f) | (pa_code(s.pa) << 5)) << 16) | ((uint64_t)(kFeatGrid | kFeatHighPrecision) << 24) |
            ((uint64_t)(elem_b & 0xf) << 28) | ((uint64_t)(mfma & 0xf) << 32) | ((uint64_t)1 << 36) |
            ((uint64_t)(s.wn & 0xf) << 40) | ((uint64_t)(s.wk & 0xf) << 44) | ((uint64_t)am_code(s.am) << 48) |
            ((uint64_t)(s.nt & 0xf) << 52) |
