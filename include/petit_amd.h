@@ -150,6 +150,18 @@ int petit_set_workspace(void *device_ptr, uint64_t bytes);
 /* Bytes a given solution needs for (m, n); 0 for solutions without split-K. */
 uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
 
+/*
+ * Native-FP4 kernels (no counterpart in the reference): MXFP4 weights go straight into the CDNA4
+ * block-scaled MFMA and the 16-bit activations are quantised on the fly to MXFP8 (e4m3 + one e8m0
+ * scale per 32 k).  That quantisation costs ~2^-4 relative per activation, so these kernels are a
+ * different accuracy class: they are NEVER chosen by PETIT_SOLUTION_AUTO and are only enumerated
+ * by petit_gemm_get_solutions after petit_enable_native_fp4(1) (or $PETIT_AMD_NATIVE_FP4=1).  Their
+ * ids carry mfma_type = 2 (the reference's unused kMatmulMfmaTypeFp8, gemm.h:20-24).  They need a
+ * registered workspace of petit_native_workspace_bytes(m, k) bytes for the quantised activations.
+ */
+int petit_enable_native_fp4(int enable);
+uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);
+
 /* Human-readable text for a return code. */
 const char *petit_error_string(int code);
 /* Layout tag of the packed tensors ("petit-cdna4/1") and library version. */

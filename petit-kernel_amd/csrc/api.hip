@@ -13,9 +13,11 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/petit_amd.h"
+#include "gemm_native.cuh"
 #include "gemm_stream.cuh"
 #include "hal.h"
 #include "layout.h"
@@ -106,7 +108,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         for (int i = 0; i < fam.count; ++i) {
             const SolutionEntry &e = fam.entries[i];
             if (e.shape.am != kTiledAm || !entry_fits(e, m, k))
-                continue;
+                continue; // (never the native-FP4 kernels: different accuracy class)
             if (!pick || (e.shape.mt == want && pick->shape.mt != want))
                 pick = &e;
         }
@@ -124,7 +126,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         if (!entry_fits(e, m, k))
             continue;
         const StreamShape &s = e.shape;
-        if (s.mt != want_mt || s.am == kTiledAm)
+        if (s.mt != want_mt || s.am == kTiledAm || s.am == kNativeAm)
             continue;
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
@@ -145,18 +147,39 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
             if (entry_fits(fam.entries[i], m, k) && fam.entries[i].shape.am != kTiledAm &&
+                fam.entries[i].shape.am != kNativeAm &&
                 (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
     }
     return best;
 }
 
+unsigned entry_mfma(const Family &fam, const SolutionEntry &e) {
+    if (e.shape.am == kNativeAm)
+        return e.a_type == kDataTypeFp16 ? kMfmaFp8ActFp16 : kMfmaFp8;
+    return fam.mfma;
+}
+uint64_t entry_id(const Family &fam, const SolutionEntry &e) {
+    return make_solution_id(e.shape, fam.elem_b, entry_mfma(fam, e), 1);
+}
 const SolutionEntry *find_entry(const Family &fam, uint64_t id) {
     const uint64_t key = solution_without_splitk(id);
     for (int i = 0; i < fam.count; ++i)
-        if (make_solution_id(fam.entries[i].shape, fam.elem_b, fam.mfma, 1) == key)
+        if (entry_id(fam, fam.entries[i]) == key)
             return &fam.entries[i];
     return nullptr;
+}
+
+// native-FP4 kernels are opt-in (own accuracy class): petit_enable_native_fp4 / $PETIT_AMD_NATIVE_FP4
+std::atomic<int> g_native_enabled{-1};
+bool native_enabled() {
+    int v = g_native_enabled.load();
+    if (v < 0) {
+        const char *e = getenv("PETIT_AMD_NATIVE_FP4");
+        v = (e && *e && *e != '0') ? 1 : 0;
+        g_native_enabled.store(v);
+    }
+    return v != 0;
 }
 
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
@@ -207,6 +230,12 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     GemmArgs args{};
     args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
     args.m = m, args.n = n, args.k = k;
+    if (entry->shape.am == kNativeAm) {
+        Workspace &ws = g_workspace[current_device()];
+        if (ws.ptr.load() == nullptr || ws.bytes.load() < native_ws_bytes(m, k))
+            return kErrKernelShape; // needs petit_set_workspace(>= petit_native_workspace_bytes(m, k))
+        args.workspace = (float *)ws.ptr.load();
+    }
     if (splitk > 1) {
         Workspace &ws = g_workspace[current_device()];
         const uint64_t need = splitk_bytes(splitk, m, n);
@@ -254,8 +283,10 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
         for (int i = 0; i < fam.count; ++i) {
             if (!entry_fits(fam.entries[i], m, k))
                 continue;
+            if (fam.entries[i].shape.am == kNativeAm && !native_enabled())
+                continue;
             if (sols && count < cap)
-                sols[count] = make_solution_id(fam.entries[i].shape, fam.elem_b, fam.mfma, 1);
+                sols[count] = entry_id(fam, fam.entries[i]);
             ++count;
         }
     }
@@ -275,7 +306,7 @@ uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned
             return tuned;
     }
     const SolutionEntry *e = heuristic(fam, m, n, k);
-    return e ? make_solution_id(e->shape, fam.elem_b, fam.mfma, 1) : 0;
+    return e ? entry_id(fam, *e) : 0;
 }
 
 int petit_repack_nvfp4_weights(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan,
@@ -309,6 +340,13 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n) {
     return splitk_bytes(solution_splitk(solution_id), m, n);
 }
 
+int petit_enable_native_fp4(int enable) {
+    g_native_enabled.store(enable ? 1 : 0);
+    return kOk;
+}
+
+uint64_t petit_native_workspace_bytes(unsigned m, unsigned k) { return native_ws_bytes(m, k); }
+
 const char *petit_error_string(int code) {
     switch (code) {
     case kOk: return "ok";
@@ -327,7 +365,7 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     if (!buf || len == 0)
         return kErrBadArgument;
     const unsigned elem_b = (unsigned)(id >> 28) & 0xf, mfma = (unsigned)(id >> 32) & 0xf;
-    const int a_type = mfma == kMfmaBf16 ? kDataTypeBf16 : kDataTypeFp16;
+    const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8) ? kDataTypeBf16 : kDataTypeFp16;
     const int b_type = elem_b == kElemBMxFp4 ? kDataTypeMxFp4e2m1 : kDataTypeFp4e2m1;
     Family fam;
     const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_entry(fam, id) : nullptr;
@@ -336,6 +374,12 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kErrKernelShape;
     }
     const StreamShape &s = e->shape;
+    if (s.am == kNativeAm) {
+        snprintf(buf, len, "native-fp4 %sxmxfp4 (activations -> mxfp8) ks%d mt%d ntw%d waves%d d%d  (wg tile %dx%d, %d threads)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.ks, s.mt, s.nt, s.wn, s.d, 16 * s.mt, 16 * s.wn * s.nt,
+                 64 * s.wn);
+        return kOk;
+    }
     if (s.am == kTiledAm) {
         snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d  (wg tile %dx%d, %d threads)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,

@@ -4,4 +4,5 @@
 #define PETIT_TU_FMT kFmtMx
 #define PETIT_TU_TABLE solutions_mx_f16
 #define PETIT_TU_NO_TILED 1
+#define PETIT_TU_NATIVE_AT Fp16
 #include "stream_tu.inc"

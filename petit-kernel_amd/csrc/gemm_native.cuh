@@ -1,0 +1,267 @@
+// gemm_native.cuh -- the native-FP4 path: MXFP4 weights fed RAW to the CDNA4 block-scaled MFMA
+// (v_mfma_scale_f32_16x16x128_f8f6f4), activations quantised on the fly to MXFP8 (e4m3 elements,
+// one e8m0 scale per 32 k).  OPT-IN: quantising 16-bit activations to e4m3 costs ~2^-4 relative
+// per element, which breaks the 1e-2 parity bar of the dequant kernels, so
+// these kernels are never chosen by solution_id = -1 and are only enumerated after
+// petit_enable_native_fp4(1).  Their own stated tolerance and exact-semantics test:
+// tests/test_gpu_parity.py::test_native_mxfp4.  NVFP4 cannot use this instruction exactly (e4m3
+// group-16 scales are not E8M0 block-32 scales), so the path exists for MXFP4 only.
+//
+// What the packed layout buys here (layout.h): a lane's 16 bytes are 32 consecutive k of one weight
+// row = exactly the FP4 operand of the instruction, and the span record byte of the tile is exactly
+// its per-lane E8M0 scale -- zero unpack VALU, one MFMA per 16x16x128 block instead of four plus 48
+// VALU.
+//
+// Operand layout of the instruction, probed on gfx950 (tools/probes/mfma_scale_probe.hip):
+//   FP4 operand : lane (row = l%16, g = l/16), regs 0-3: k = 32g + 8r + nibble (natural).
+//   FP8 operand : lane (col = l%16, g = l/16), regs 0-3: k = 16g .. 16g+15, regs 4-7: k = 64+16g ..
+//   scales      : block b (k in [32b, 32b+32)) takes its E8M0 byte from lane group g = b of the same
+//                 row / column, whichever lane holds the data bytes; opsel picks the byte of the VGPR.
+//
+// Two launches: quantize_act_kernel (A -> fp8 bytes in the operand's order + scales, into the
+// registered workspace) and gemm_native_kernel (tiled like gemm_tiled.cuh, A tile through LDS).
+#pragma once
+
+#include "gemm_tiled.cuh"
+
+namespace petit_amd {
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// Workspace layout: qa[M][K] bytes (per 128-k tile: byte 32g + 16c + j holds k = 64c + 16g + j),
+// then qs[M][K/32] E8M0 bytes.
+__host__ __device__ inline size_t native_ws_bytes(unsigned m, unsigned k) { return (size_t)m * k + (size_t)m * (k / 32); }
+
+// One thread = 8 consecutive k of one row; the 4 threads of a quad share one 32-k block.
+template <class AT>
+__global__ __launch_bounds__(256) void quantize_act_kernel(const void *a, unsigned char *ws, unsigned m, unsigned k) {
+    const size_t units = (size_t)m * (k / 8);
+    unsigned char *qa = ws;
+    unsigned char *qs = ws + (size_t)m * k;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const unsigned row = (unsigned)(u / (k / 8)), c8 = (unsigned)(u % (k / 8)); // 8-element column
+        const u32x4 raw = reinterpret_cast<const u32x4 *>(a)[u];
+        float v[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = raw[d];
+            if constexpr (AT::kType == kDataTypeBf16) {
+                const unsigned lo = w << 16, hi = w & 0xffff0000u;
+                v[2 * d] = __builtin_bit_cast(float, lo);
+                v[2 * d + 1] = __builtin_bit_cast(float, hi);
+            } else {
+                const f16x2 p = __builtin_bit_cast(f16x2, w);
+                v[2 * d] = (float)p[0];
+                v[2 * d + 1] = (float)p[1];
+            }
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            amax = fmaxf(amax, fabsf(v[i]));
+        // block maximum over the quad (k/8 is a multiple of 4 and rows start on quad boundaries)
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        // E8M0 scale 2^(E-7): the block maximum lands in [128, 256) <= 448 (e4m3 max)
+        const unsigned ebits = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+        unsigned sbyte = amax == 0.f ? 127u : (ebits > 7u ? ebits - 7u : 1u);
+        sbyte = sbyte > 254u ? 254u : sbyte;
+        const float inv = __builtin_bit_cast(float, (254u - sbyte) << 23); // 2^-(sbyte-127)
+        int q0 = 0, q1 = 0;
+        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, q0, false);
+        q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, q0, true);
+        q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, q1, false);
+        q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, q1, true);
+        // position inside the 128-k tile in the FP8 operand's order
+        const unsigned kt = c8 / 16, col16 = c8 % 16;
+        const unsigned off = 32 * ((col16 & 7) >> 1) + 16 * (col16 >> 3) + 8 * (col16 & 1);
+        uint2 o;
+        o.x = (unsigned)q0, o.y = (unsigned)q1;
+        *reinterpret_cast<uint2 *>(qa + (size_t)row * k + kt * 128 + off) = o;
+        if ((c8 & 3) == 0)
+            qs[(size_t)row * (k / 32) + c8 / 4] = (unsigned char)sbyte;
+    }
+}
+
+//   MT, NTW, WAVES, D as in TiledCfg.  A tile image in LDS: BM rows x (128 data + 4 scale + 12 pad) B.
+template <class AT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct NativeCfg {
+    using AT = AT_;
+    static constexpr int KS = KS_, MT = MT_, NTW = NTW_, WAVES = WAVES_, D = D_;
+    static constexpr int kThreads = 64 * WAVES;
+    static constexpr int BM = 16 * MT;
+    static constexpr int kRowU4 = 9;                         // 8 data units + 1 unit holding the 4 scales
+    static constexpr int kBufU4 = BM * kRowU4;
+    static constexpr int kUnitsPerThread = BM * 8 / kThreads; // data units (16 B) per thread per tile
+    static_assert(KS % D == 0, "ring depth must divide the span");
+    static_assert((BM * 8) % kThreads == 0 && BM <= kThreads, "A tile must split evenly over the workgroup");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmArgs p, const unsigned char *ws) {
+    using AT = typename Cfg::AT;
+    constexpr int KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
+    constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;
+    constexpr unsigned kOob = 0x80000000u;
+    constexpr int UPT = Cfg::kUnitsPerThread;
+
+    __shared__ u32x4 smem[2 * Cfg::kBufU4];
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned r = lane & 15u, g = lane >> 4;
+
+    const unsigned ktiles = p.k / kTileK;
+    const unsigned nspans = ktiles / KS;
+    const unsigned ntiles = p.n / kTileN;
+    const unsigned nt0 = (blockIdx.x * WAVES + wave) * NTW;
+    const unsigned m0 = blockIdx.y * Cfg::BM;
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)NTW, ntiles - nt0) : 0u;
+    const unsigned w_row_bytes = ktiles * kTileBytes;
+    const unsigned s_row_bytes = p.k / 2;
+    const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
+    const unsigned nt_base = valid_nt ? nt0 : 0u;
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        make_rsrc((const char *)p.w + (size_t)nt_base * w_row_bytes, valid_nt * w_row_bytes);
+    const __amdgpu_buffer_rsrc_t s_rsrc =
+        make_rsrc((const char *)p.s + (size_t)nt_base * s_row_bytes, valid_nt * s_row_bytes);
+    // quantised activations and their scales (rows beyond M read as zeros: 0 * 2^-127)
+    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * p.k, rows * p.k);
+    const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + (size_t)p.m * p.k + (size_t)m0 * (p.k / 32), rows * (p.k / 32));
+
+    unsigned w_voff[NTW], s_voff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + nt * w_row_bytes : kOob;
+        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + nt * s_row_bytes : kOob;
+    }
+    // staging: data unit u = tid + i*kThreads -> row u/8, unit u%8; scale dword: thread t < BM -> row t
+    unsigned a_g_voff[UPT], a_l_idx[UPT];
+#pragma unroll
+    for (int i = 0; i < UPT; ++i) {
+        const unsigned u = tid + i * Cfg::kThreads, row = u >> 3, col = u & 7u;
+        a_g_voff[i] = row * p.k + col * 16;
+        a_l_idx[i] = row * Cfg::kRowU4 + col;
+    }
+    const bool has_scale_row = tid < (unsigned)Cfg::BM;
+    const unsigned qs_voff = has_scale_row ? tid * (p.k / 32) : kOob;
+    unsigned *const smem_u32 = reinterpret_cast<unsigned *>(smem);
+    const unsigned qs_l_idx = (tid * Cfg::kRowU4 + 8) * 4; // dword index of the row's scale unit
+    const unsigned a_frag_base = r * Cfg::kRowU4 + g * 2;  // + mt*16*kRowU4 (+1 for the second half)
+    const unsigned a_scale_byte = (r * Cfg::kRowU4 + 8) * 16 + g; // byte index of this lane's block scale
+
+    u32x4 astage[UPT];
+    unsigned sstage = 0;
+    auto load_stage = [&](unsigned kt) {
+#pragma unroll
+        for (int i = 0; i < UPT; ++i)
+            astage[i] = buf_load16(qa_rsrc, a_g_voff[i], kt * 128, kAuxDefault);
+        sstage = __builtin_amdgcn_raw_buffer_load_b32(qs_rsrc, qs_voff, kt * 4, 0);
+    };
+    auto store_stage = [&](unsigned buf) {
+        u32x4 *const dst = smem + buf * Cfg::kBufU4;
+#pragma unroll
+        for (int i = 0; i < UPT; ++i)
+            dst[a_l_idx[i]] = astage[i];
+        if (has_scale_row)
+            smem_u32[buf * Cfg::kBufU4 * 4 + qs_l_idx] = sstage;
+    };
+
+    load_stage(0);
+    ScaleRec<kFmtMx, KS> srec[NTW], srec_next[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[nt], 0u);
+    u32x4 wring[D][NTW];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], i * kTileBytes, kAuxDefault);
+    store_stage(0);
+    __syncthreads();
+
+    auto span_body = [&](const unsigned sp, auto last_c) {
+        constexpr bool kLast = decltype(last_c)::value;
+        const unsigned kt0 = sp * KS;
+        if constexpr (!kLast) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                srec_next[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[nt], (sp + 1) * 64 * kRecBytes);
+        }
+        static_for<0, KS>([&](auto t_c) {
+            constexpr int T = decltype(t_c)::value;
+            constexpr int SLOT = T % D;
+            constexpr bool kRefill = !kLast || (T + D < KS);
+            constexpr bool kNextA = !kLast || (T + 1 < KS);
+            const unsigned kt = kt0 + T;
+            const unsigned cur = kt & 1u;
+            const u32x4 *const a_cur = smem + cur * Cfg::kBufU4;
+            const unsigned char *const a_cur_bytes = reinterpret_cast<const unsigned char *>(a_cur);
+            if constexpr (kNextA)
+                load_stage(kt + 1);
+            // weights: the lane's uint4 IS the FP4 operand; its scale is byte T of the span record
+            i32x8 wop[NTW];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const u32x4 w = wring[SLOT][nt];
+                wop[nt] = i32x8{(int)w[0], (int)w[1], (int)w[2], (int)w[3], 0, 0, 0, 0};
+            }
+            if constexpr (kRefill) {
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxDefault);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4 lo = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4];
+                const u32x4 hi = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + 1];
+                const int ascale = (int)a_cur_bytes[a_scale_byte + mt * 16 * Cfg::kRowU4 * 16];
+                const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                        wop[nt], aop, acc[mt][nt], 4 /* A = FP4 */, 0 /* B = FP8 e4m3 */, T % 4,
+                        (int)srec[nt].d[T / 4], 0, ascale);
+            }
+            if constexpr (kNextA) {
+                store_stage(cur ^ 1u);
+                __syncthreads();
+            }
+        });
+        if constexpr (!kLast) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                srec[nt] = srec_next[nt];
+        }
+    };
+    for (unsigned sp = 0; sp + 1 < nspans; ++sp)
+        span_body(sp, std::false_type{});
+    span_body(nspans - 1, std::true_type{});
+
+    const float gs = *p.gs;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const unsigned m = m0 + mt * 16 + r;
+            const unsigned n = (nt0 + nt) * 16 + g * 4;
+            if (m < p.m && (unsigned)nt < valid_nt) {
+                const f32x4 v = acc[mt][nt];
+                uint2 o;
+                o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
+                o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
+                *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = o;
+            }
+        }
+}
+
+} // namespace petit_amd

@@ -23,6 +23,9 @@
 //                                 through wave-private LDS (AM in gemm_stream.cuh);
 //                                 5/6/7 = the same staged paths on the fp16 pipeline
 //                                 with block-floating-point activations (bf16 x NVFP4),
+//                                 9 = the native-FP4 kernel (gemm_native.cuh; mfma_type
+//                                 nibble = 2, the reference's unused kMatmulMfmaTypeFp8,
+//                                 bit 35 set when the activations are fp16),
 //                                 8 = the tiled large-M kernel (gemm_tiled.cuh), whose
 //                                 fields read: tile_m = MT, warp_partition_n = WAVES,
 //                                 bits 52-55 = NTW, warp_partition_k = 1
@@ -40,7 +43,7 @@ namespace petit_amd {
 
 enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
 enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u };
-enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u };
+enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u };
 
 struct StreamShape {
     int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel
@@ -48,12 +51,15 @@ struct StreamShape {
 };
 constexpr unsigned pa_code(int pa) { return pa == 8 ? 3u : pa == 4 ? 2u : pa == 2 ? 1u : 0u; }
 constexpr int kTiledAm = -1;
+// the native-FP4 kernels (gemm_native.cuh): MXFP4 weights straight into the block-scaled MFMA,
+// activations quantised to MXFP8; opt-in, never a default
+constexpr int kNativeAm = -2;
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
 // per-span block floating point (Bf16Bfp in gemm_stream.cuh); codes 5 / 6 / 7
 constexpr int kBfpAm = 100;
 constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {
-    return am == kTiledAm ? 8u : am == 0 ? 0u : (am_rows(am) == 1 ? 1u : am_rows(am) == 2 ? 2u : 3u) + (am >= kBfpAm ? 4u : 0u);
+    return am == kNativeAm ? 9u : am == kTiledAm ? 8u : am == 0 ? 0u : (am_rows(am) == 1 ? 1u : am_rows(am) == 2 ? 2u : 3u) + (am >= kBfpAm ? 4u : 0u);
 }
 
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {

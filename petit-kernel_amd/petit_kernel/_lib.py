@@ -46,6 +46,8 @@ _SIGNATURES = {
     "petit_repack_mxfp4_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "petit_set_workspace": (C.c_int, [C.c_void_p, C.c_uint64]),
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
+    "petit_enable_native_fp4": (C.c_int, [C.c_int]),
+    "petit_native_workspace_bytes": (C.c_uint64, [C.c_uint, C.c_uint]),
     "petit_error_string": (C.c_char_p, [C.c_int]),
     "petit_layout_tag": (C.c_char_p, []),
     "petit_version": (C.c_char_p, []),

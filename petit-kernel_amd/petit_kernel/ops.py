@@ -218,3 +218,32 @@ def get_fp4_solutions(*args) -> list:
 
 
 get_nvfp4_solutions = get_fp4_solutions
+
+
+# --- native-FP4 path (no counterpart in the reference; opt-in, see include/petit_amd.h) -------------
+
+def enable_native_fp4(enable: bool = True) -> None:
+    """Let get_fp4_solutions enumerate the native block-scaled-MFMA kernels (MXFP4 weights only;
+    activations are quantised to MXFP8 on the fly, a different accuracy class)."""
+    _lib.lib.petit_enable_native_fp4(int(bool(enable)))
+
+
+def native_workspace_bytes(size_m: int, size_k: int) -> int:
+    return int(_lib.lib.petit_native_workspace_bytes(size_m, size_k))
+
+
+_workspace_keepalive = {}
+
+
+def set_workspace(buf) -> None:
+    """Register (or with None, unregister) a device scratch tensor for kernels that need one
+    (split-K slabs, quantised activations of the native path).  The tensor is kept alive here."""
+    if buf is None:
+        with torch.cuda.device(torch.cuda.current_device()):
+            _lib.lib.petit_set_workspace(None, 0)
+        _workspace_keepalive.pop(torch.cuda.current_device(), None)
+        return
+    _check(buf.is_cuda and buf.is_contiguous(), "workspace must be a contiguous GPU tensor")
+    with torch.cuda.device(buf.device):
+        _lib.lib.petit_set_workspace(_ptr(buf), C.c_uint64(buf.numel() * buf.element_size()))
+        _workspace_keepalive[buf.device.index] = buf

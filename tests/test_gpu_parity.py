@@ -323,3 +323,61 @@ def test_llama70b_shapes_properties(pk, n, k):
     dq = O.dequant_nvfp4(q[rows], s[rows])
     _, cf = O.gemm_ref(bits(a8), True, dq, 1.0)
     check_gemm(bits(c8[:, torch.from_numpy(rows).to(DEV)]), cf, True)
+
+
+# --- the native-FP4 path (opt-in): exact semantics + its own stated tolerance ---------------------
+
+def quantize_act_mxfp8(a_f32: np.ndarray) -> np.ndarray:
+    """CPU statement of quantize_act_kernel (csrc/gemm_native.cuh): per 32-k block, E8M0 scale
+    2^(E-7) with E the exponent of the block maximum, elements rounded to e4m3 (RNE).  Returns the
+    DEQUANTISED activations (exactly representable in bf16: 4 significant bits x power of two)."""
+    m, k = a_f32.shape
+    blk = a_f32.reshape(m, k // 32, 32)
+    amax = np.abs(blk).max(axis=2)
+    ebits = (amax.astype(np.float32).view(np.uint32) >> 23) & 0xFF
+    sbyte = np.where(amax == 0, 127, np.clip(ebits.astype(np.int64) - 7, 1, 254))
+    scale = np.ldexp(1.0, sbyte - 127).astype(np.float32)[:, :, None]
+    q = torch.from_numpy((blk / scale).astype(np.float32)).to(torch.float8_e4m3fn).float().numpy()
+    return (q * scale).reshape(m, k)
+
+
+@pytest.mark.parametrize("is_bf16", [True, False])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512)])
+def test_native_mxfp4(pk, m, n, k, is_bf16):
+    a_bits, q, s, gs = random_problem("mx", m, n, k, 4242 + m + n + k, is_bf16)
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = dtype
+    h.b_type = pk.DataType.mxfloat4_e2m1
+    pk.ops.enable_native_fp4(False)
+    assert all((sid >> 32) & 7 != 2 for sid in pk.ops.get_fp4_solutions(h, m, n, k))   # opt-in only
+    pk.ops.enable_native_fp4(True)
+    try:
+        native = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 32) & 7 == 2]
+        assert native
+        pk.ops.set_workspace(None)
+        with pytest.raises(RuntimeError, match="No kernel implementation"):
+            run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, native[0])       # no workspace registered
+        ws = torch.empty(pk.ops.native_workspace_bytes(m, k), dtype=torch.uint8, device=DEV)
+        pk.ops.set_workspace(ws)
+        a_f32 = to_f32(a_bits, is_bf16)
+        a_q = quantize_act_mxfp8(a_f32)
+        dq = O.dequant_mxfp4(q, s)
+        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq, gs)               # same quantised activations
+        _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)                              # unquantised activations
+        sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        for sid in native:
+            c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sid), is_bf16).astype(np.float64)
+            fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
+            # (1) the kernel computes exactly "MXFP8(activations) x MXFP4(weights)": only the f32
+            #     accumulation order and the final 16-bit rounding separate it from the oracle
+            err = np.abs(c - exact)[fin]
+            assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all()
+            # (2) stated tolerance of the path against the UNQUANTISED reference: e4m3 activations carry
+            #     up to 2^-4 relative error each; on these random problems the result stays within 2 %
+            #     of sum|a||w| (and typically ~3 % of the output's rms)
+            assert (np.abs(c - full)[fin] <= 2e-2 * sum_abs[fin] + 1e-2).all()
+            assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 6e-2 * np.sqrt(np.mean(full[fin] ** 2))
+    finally:
+        pk.ops.set_workspace(None)
+        pk.ops.enable_native_fp4(False)
