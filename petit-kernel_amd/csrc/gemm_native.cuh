@@ -28,6 +28,18 @@ namespace petit_amd {
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+// Pins an accumulator at this program point (device pass only: the host pass has no "a" registers).
+// hipcc 7.2 does not treat the block-scaled MFMA builtin as convergent and sinks it into the
+// lane-divergent `if (m < M)` of the epilogue; there EXEC masks off the lanes of the absent rows and
+// the instruction, which reads the weight rows from ALL lanes, sees garbage for them (wrong results
+// in every partial m-tile).  Found with per-step register dumps; tools/probes/mfma_scale_hazard.hip
+// rules out the VALU -> scale-operand hazards.
+__device__ __forceinline__ void pin_acc(f32x4 &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+a"(x));
+#endif
+}
+
 // Workspace layout: qa[M][K] bytes (per 128-k tile: byte 32g + 16c + j holds k = 64c + 16g + j),
 // then qs[M][K/32] E8M0 bytes.
 __host__ __device__ inline size_t native_ws_bytes(unsigned m, unsigned k) { return (size_t)m * k + (size_t)m * (k / 32); }
@@ -104,7 +116,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
     constexpr unsigned kOob = 0x80000000u;
     constexpr int UPT = Cfg::kUnitsPerThread;
 
-    __shared__ u32x4 smem[2 * Cfg::kBufU4];
+    // two tile images + one junk dword per thread: threads without a scale row store there, so the
+    // staging code is branch-free and every k-step stays one basic block (see the note at the MFMAs)
+    __shared__ u32x4 smem[2 * Cfg::kBufU4 + Cfg::kThreads / 4];
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -154,7 +168,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
     const bool has_scale_row = tid < (unsigned)Cfg::BM;
     const unsigned qs_voff = has_scale_row ? tid * (p.k / 32) : kOob;
     unsigned *const smem_u32 = reinterpret_cast<unsigned *>(smem);
-    const unsigned qs_l_idx = (tid * Cfg::kRowU4 + 8) * 4; // dword index of the row's scale unit
+    // dword index of the row's scale unit in image 0 / image 1 (junk slot for threads without a row)
+    const unsigned qs_l_idx0 = has_scale_row ? (tid * Cfg::kRowU4 + 8) * 4 : 2 * Cfg::kBufU4 * 4 + tid;
+    const unsigned qs_l_idx1 = has_scale_row ? qs_l_idx0 + Cfg::kBufU4 * 4 : qs_l_idx0;
     const unsigned a_frag_base = r * Cfg::kRowU4 + g * 2;  // + mt*16*kRowU4 (+1 for the second half)
     const unsigned a_scale_byte = (r * Cfg::kRowU4 + 8) * 16 + g; // byte index of this lane's block scale
 
@@ -171,8 +187,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
 #pragma unroll
         for (int i = 0; i < UPT; ++i)
             dst[a_l_idx[i]] = astage[i];
-        if (has_scale_row)
-            smem_u32[buf * Cfg::kBufU4 * 4 + qs_l_idx] = sstage;
+        smem_u32[buf ? qs_l_idx1 : qs_l_idx0] = sstage;
     };
 
     load_stage(0);
@@ -236,6 +251,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
                 store_stage(cur ^ 1u);
                 __syncthreads();
             }
+            // Pin the step: left alone, LLVM sinks all MT*NTW*KS MFMAs of a span below its last barrier
+            // and hoists every step's LDS traffic above them (hundreds of spilled VGPRs, no overlap).
+            __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (!kLast) {
 #pragma unroll
@@ -246,6 +264,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
     for (unsigned sp = 0; sp + 1 < nspans; ++sp)
         span_body(sp, std::false_type{});
     span_body(nspans - 1, std::true_type{});
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            pin_acc(acc[mt][nt]); // every MFMA executes with all 64 lanes, before the divergent stores
 
     const float gs = *p.gs;
 #pragma unroll
