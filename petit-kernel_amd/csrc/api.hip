@@ -93,30 +93,37 @@ uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
 // a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
 const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k) {
     // Rules distilled from the MI355X sweeps (profiles/):
-    //  * M <= 4: stage the activations through LDS (AM = smallest that holds M);
+    //  * M <= 16: stage the activations through LDS (AM = smallest that holds M);
     //  * what saturates HBM is bytes in flight: as many resident waves as the grid
     //    allows, every wave with its whole ring outstanding -> pick the shape whose
     //    wave count is closest to (but preferably above) 4 waves per SIMD;
-    //  * 5 <= M <= 16: two n-tiles per wave halve the activation re-reads;
+    //  * 5 <= M <= 16: two n-tiles per wave halve the activation traffic;
     //  * larger M: more m-tiles per workgroup, capped by registers.
     const ArchInfo &arch = arch_info(current_device());
     const unsigned ntiles = n / kTileN;
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
-    if (m >= 48) { // MFMA-bound regime: the tiled kernel, 128-row tiles once M fills them
+    if (m >= 48) { // MFMA-bound regime: the tiled kernel, 128-row tiles once M fills them -- provided its
+                   // grid fills the chip (it has no K split): at N = 8192 that needs M >= 256, below
+                   // that the streaming kernel with 4 m-tiles per workgroup is 2-3x faster (r01 sweeps)
         const int want = m >= 96 ? 8 : 4;
         const SolutionEntry *pick = nullptr;
+        unsigned pick_wgs = 0;
         for (int i = 0; i < fam.count; ++i) {
             const SolutionEntry &e = fam.entries[i];
             if (e.shape.am != kTiledAm || !entry_fits(e, m, k))
                 continue; // (never the native-FP4 kernels: different accuracy class)
-            if (!pick || (e.shape.mt == want && pick->shape.mt != want))
-                pick = &e;
+            const unsigned per_wg = e.shape.nt * e.shape.wn;
+            const unsigned wgs = ((m + 16 * e.shape.mt - 1) / (16 * e.shape.mt)) * ((ntiles + per_wg - 1) / per_wg);
+            const bool fills = wgs * 4 >= arch.num_cus * 3, pick_fills = pick_wgs * 4 >= arch.num_cus * 3;
+            if (!pick || (fills && !pick_fills) ||
+                (fills == pick_fills && e.shape.mt == want && pick->shape.mt != want))
+                pick = &e, pick_wgs = wgs;
         }
-        if (pick)
+        if (pick && (pick_wgs * 4 >= arch.num_cus * 3 || m > 256))
             return pick;
     }
     const int want_mt = m <= 16 ? 1 : m <= 32 ? 2 : 4;
-    const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 0;
+    const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : 0;
     const int want_nt = m <= 4 ? 1 : 2;
     const double target_waves = (double)arch.num_cus * 4 * 4;
     const SolutionEntry *best = nullptr;

@@ -254,10 +254,11 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 //   WN,WK waves along N / K in the workgroup
 //   D     ring depth (tiles in flight per n-tile), D divides KS
 //   AM    activation path: 0 = fragment-shaped loads straight from L2 (any M);
-//         1, 2, 4 = the wave stages AM rows x one span of A in its private LDS
+//         1, 2, 4, 8, 16 = the wave stages AM rows x SL tiles of A in its private LDS
 //         slice with fully coalesced loads and reads MFMA fragments back with
-//         ds_read_b128 (M <= AM; needs MT == 1).  Measured on MI355X at M = 1,
-//         8192^2: the 36 four-lane buffer_loads per span of the direct path cost
+//         ds_read_b128 (M <= AM; needs MT == 1).  SL = one span for AM <= 4, and 4 / 2
+//         tiles for AM = 8 / 16 (8 KiB per wave either way).  Measured on MI355X at
+//         M = 1, 8192^2: the 36 four-lane buffer_loads per span of the direct path cost
 //         3 us of a 12 us launch (TA issue-bound), see DESIGN.md.
 //   ABL   ablation bits for tools/ablate (0 in every shipped kernel):
 //         1 no activation loads, 2 no unpack, 4 no MFMA, 8 empty kernel
@@ -270,16 +271,22 @@ struct StreamCfg {
     static constexpr int PA = PA_;
     static_assert(KS % PA_ == 0 && PA_ >= 1, "activation prefetch distance must divide the span");
     static constexpr int kThreads = 64 * WN * WK;
-    // one staged activation row: KS tiles x 256 B, padded by one 16-byte slot so
+    // stage length in tiles: a whole span while that is <= 8 KiB per wave, else 32 / AM tiles
+    static constexpr int kStageRows = 32; // rows x tiles per stage (8 KiB per wave; 16 KiB measured slower)
+    static constexpr int SL = (AM <= 4) ? KS : ((kStageRows / (AM > 0 ? AM : 1)) < KS ? kStageRows / (AM > 0 ? AM : 1) : KS);
+    // one staged activation row: SL tiles x 256 B, padded by one 16-byte slot so
     // that the rows a ds_read_b128 lane group touches fall on different banks
-    static constexpr int kARowU4 = KS * 16 + 1;
+    static constexpr int kARowU4 = SL * 16 + 1;
     static constexpr int kSplitN = AT::kSplit ? 2 : 1;                 // hi / lo images of A
     static constexpr int kALdsU4 = AM * kARowU4 * kSplitN;             // per wave
     static constexpr int kRedItems = WN * MT * NT * 64;                // float4 outputs per workgroup
     static constexpr int kSmemU4 = WN * WK * kALdsU4 + (WK > 1 ? WK * kRedItems : 0);
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(kThreads <= 1024, "workgroup too large");
-    static_assert(AM == 0 || (MT == 1 && (AM == 1 || AM == 2 || AM == 4)), "staged path: MT == 1, AM in {1,2,4}");
+    static_assert(AM == 0 || (MT == 1 && (AM == 1 || AM == 2 || AM == 4 || AM == 8 || AM == 16)),
+                  "staged path: MT == 1, AM in {1,2,4,8,16}");
+    static_assert(AM <= 4 || (!AT::kSplit && !AT::kBfp), "AM = 8 / 16: plain bf16 / fp16 activations only");
+    static_assert(AM == 0 || KS % SL == 0, "stage length must divide the span");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(!AT::kBfp || (AM > 0 && KS >= 4 && FMT == 0), "block-floating-point A: staged NVFP4 path only");
 };
@@ -365,21 +372,23 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         // records, then the W ring
         u32x4 *const a_lds = smem + wave * Cfg::kALdsU4;               // staged path only
         const unsigned a_frag_base = ((r < (unsigned)AM) ? r : 0u) * Cfg::kARowU4 + g * 4;
-        constexpr int kAStageLoads = AM * KS / 4;                      // 1 KiB per wave-load
-        u32x4 astage[kAStageLoads > 0 ? kAStageLoads : 1];             // next span, in flight
-        auto issue_a_stage = [&](unsigned sp, bool ok) {
+        constexpr int SL = Cfg::SL;                                    // tiles per stage
+        constexpr int kAStageLoads = AM * SL / 4;                      // 1 KiB per wave-load
+        u32x4 astage[kAStageLoads > 0 ? kAStageLoads : 1];             // next stage, in flight
+        // stage `st` = tiles [st*SL, st*SL + SL) of K (absolute index: span * (KS/SL) + stage in span)
+        auto issue_a_stage = [&](unsigned st, bool ok) {
             (void)ok;
             if constexpr (AM > 0 && (ABL & 1) == 0) {
 #pragma unroll
                 for (int i = 0; i < kAStageLoads; ++i) {
                     unsigned vo;
-                    if constexpr (KS >= 4) { // a row of the span is KS/4 whole wave-loads
-                        constexpr int kPerRow = KS / 4;
+                    if constexpr (SL >= 4) { // a row of the stage is SL/4 whole wave-loads
+                        constexpr int kPerRow = SL / 4;
                         vo = (i / kPerRow) * p.k * 2 + (i % kPerRow) * 1024 + lane * 16;
-                    } else { // KS == 2: one wave-load covers two rows of 512 B
+                    } else { // SL == 2: one wave-load covers two rows of 512 B
                         vo = (2 * i + (lane >> 5)) * p.k * 2 + (lane & 31u) * 16;
                     }
-                    astage[i] = buf_load16(a_rsrc, vo, sp * (KS * 256), kAuxDefault);
+                    astage[i] = buf_load16(a_rsrc, vo, st * (SL * 256), kAuxDefault);
                 }
             }
         };
@@ -427,8 +436,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
                 for (int i = 0; i < kAStageLoads; ++i) {
                     unsigned dst;
-                    if constexpr (KS >= 4) {
-                        constexpr int kPerRow = KS / 4;
+                    if constexpr (SL >= 4) {
+                        constexpr int kPerRow = SL / 4;
                         dst = (i / kPerRow) * Cfg::kARowU4 + (i % kPerRow) * 64 + lane;
                     } else {
                         dst = (2 * i + (lane >> 5)) * Cfg::kARowU4 + (lane & 31u);
@@ -445,8 +454,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             }
         };
         if constexpr (AM > 0) {
-            static_assert(AM * KS >= 4, "staged path needs at least one full wave-load per span");
-            issue_a_stage(sp_begin, true);
+            static_assert(AM * SL >= 4, "staged path needs at least one full wave-load per stage");
+            issue_a_stage(sp_begin * (KS / SL), true);
         }
         ScaleRec<FMT, KS> srec[NT];
 #pragma unroll
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                             aring[i][mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt_begin + i) * 256, kAuxDefault);
                     }
         }
-        auto load_first_frags = [&]() { // fragments of tile 0 of the span now in LDS
+        auto load_first_frags = [&]() { // fragments of tile 0 of the stage now in LDS
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (ABL & 1)
@@ -488,8 +497,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             }
         };
         if constexpr (AM > 0) {
-            write_a_stage(); // first span's activations -> LDS
+            write_a_stage(); // first stage's activations -> LDS
             load_first_frags();
+            if constexpr (SL < KS)
+                issue_a_stage(sp_begin * (KS / SL) + 1, true);
         }
 
         // One span (KS tiles).  kLast: the wave's final span -- nothing further is
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             constexpr bool kLast = decltype(last_c)::value;
             const unsigned kt0 = sp * KS;
             if constexpr (!kLast) {
-                if constexpr (AM > 0)
+                if constexpr (AM > 0 && SL == KS)
                     issue_a_stage(sp + 1, true); // held in VGPRs until this span's fragments are read
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -519,15 +530,17 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 // step's straight from L2 (direct path)
                 u32x4 anext[MT][4];
                 u32x4 anext_lo[AT::kSplit && AM > 0 ? 4 : 1];
+                // does the next tile live in the stage that is in LDS now?
+                constexpr bool kNextInStage = (T + 1 < KS) && ((T + 1) % SL != 0);
                 if constexpr (AM > 0) {
                     // staged path: prefetch the NEXT tile's fragments now, so the LDS
                     // latency hides behind this tile's unpack instead of stalling each MFMA
-                    if constexpr (T + 1 < KS) {
+                    if constexpr (kNextInStage) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            anext[0][j] = (ABL & 1) ? afrag[0][j] : a_lds[a_frag_base + (T + 1) * 16 + j];
+                            anext[0][j] = (ABL & 1) ? afrag[0][j] : a_lds[a_frag_base + ((T + 1) % SL) * 16 + j];
                             if constexpr (AT::kSplit)
-                                anext_lo[j] = a_lds[a_frag_base + AM * Cfg::kARowU4 + (T + 1) * 16 + j];
+                                anext_lo[j] = a_lds[a_frag_base + AM * Cfg::kARowU4 + ((T + 1) % SL) * 16 + j];
                         }
                         __builtin_amdgcn_sched_barrier(0); // keep the reads at the top of the step
                     }
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                         for (int j = 0; j < 4; ++j)
                             aring[T % PA][mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, (kt + PA) * 256, kAuxDefault);
                 }
-                if constexpr (AM > 0 && T + 1 < KS) {
+                if constexpr (AM > 0 && kNextInStage) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         afrag[0][j] = anext[0][j];
@@ -601,6 +614,16 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                         for (int j = 0; j < 4; ++j)
                             afrag_lo[j] = anext_lo[j];
                     }
+                }
+                if constexpr (AM > 0 && SL < KS && (T + 1) % SL == 0 && (T + 1 < KS || !kLast)) {
+                    // stage boundary inside (or at the end of) the span: every fragment of the old
+                    // stage has been read (LDS is in order within a wave), so the slice takes the
+                    // stage held in VGPRs, and the one after it is requested
+                    write_a_stage();
+                    load_first_frags();
+                    const unsigned st_next = (kt + 1) / SL + 1;
+                    if constexpr (!kLast || (T + 1 + SL < KS))
+                        issue_a_stage(st_next, true);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -617,7 +640,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             if constexpr (!kLast) {
                 // every fragment of this span has been read (LDS is in order within a
                 // wave): the slice can take the next span's activations
-                if constexpr (AM > 0) {
+                if constexpr (AM > 0 && SL == KS) {
                     write_a_stage();
                     load_first_frags();
                 }

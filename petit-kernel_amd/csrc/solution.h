@@ -20,7 +20,8 @@
 //   bits 48-51  warp_partition    the reference's NK(0)/Cooperative(1) enum, never 1 in
 //                                 its shipped table; here: activation path,
 //                                 0 = direct L2 fragments, 1/2/3 = 1/2/4 rows staged
-//                                 through wave-private LDS (AM in gemm_stream.cuh);
+//                                 through wave-private LDS (AM in gemm_stream.cuh),
+//                                 10/11 = 8/16 rows staged the same way;
 //                                 5/6/7 = the same staged paths on the fp16 pipeline
 //                                 with block-floating-point activations (bf16 x NVFP4),
 //                                 9 = the native-FP4 kernel (gemm_native.cuh; mfma_type
@@ -59,7 +60,12 @@ constexpr int kNativeAm = -2;
 constexpr int kBfpAm = 100;
 constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {
-    return am == kNativeAm ? 9u : am == kTiledAm ? 8u : am == 0 ? 0u : (am_rows(am) == 1 ? 1u : am_rows(am) == 2 ? 2u : 3u) + (am >= kBfpAm ? 4u : 0u);
+    return am == kNativeAm ? 9u
+           : am == kTiledAm ? 8u
+           : am == 0        ? 0u
+           : am == 8        ? 10u
+           : am == 16       ? 11u
+                            : (am_rows(am) == 1 ? 1u : am_rows(am) == 2 ? 2u : 3u) + (am >= kBfpAm ? 4u : 0u);
 }
 
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {

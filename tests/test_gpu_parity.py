@@ -242,7 +242,7 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256)])
+@pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256), (7, 96, 2048)])
 @pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
 def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
     """The counterpart of the reference's one-gtest-per-tile-shape list

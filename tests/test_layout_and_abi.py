@@ -81,9 +81,9 @@ def test_cxx_header_compiles_against_the_c_abi(tmp_path):
     src.write_text('#include "causalflow/petit/gemm.h"\n'
                    "using namespace causalflow::petit::rocm::quantization;\n"
                    "int main() { PetitSolutionHints h{kDataTypeBf16, kDataTypeFp4e2m1, kDataTypeBf16, false};\n"
-                   "  unsigned n = 0; SolutionId ids[64];\n"
+                   "  unsigned n = 0; SolutionId ids[256];\n"
                    "  if (fp4::GemmGetSolutions(h, 1, 8192, 8192, nullptr, &n) != 0) return 1;\n"
-                   "  if (n == 0 || n > 64) return 2; if (fp4::GemmGetSolutions(h, 1, 8192, 8192, ids, &n)) return 3;\n"
+                   "  if (n == 0 || n > 256) return 2; if (fp4::GemmGetSolutions(h, 1, 8192, 8192, ids, &n)) return 3;\n"
                    "  static_assert(sizeof(SolutionId) == 8, \"\");\n"
                    "  return ids[0].element_b == kMatmulTypeBNvFp4 && ids[0].mfma_type == kMatmulMfmaTypeBf16 ? 0 : 4; }\n")
     from petit_kernel import _lib

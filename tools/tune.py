@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--compare-dense", action="store_true",
                     help="also time torch.matmul (hipBLASLt/rocBLAS) on a dense 16-bit weight of the same shape")
     ap.add_argument("--rotate-mb", type=int, default=1280, help="rotate over at least this many MB of distinct weights")
+    ap.add_argument("--native", action="store_true",
+                    help="also enumerate the opt-in native-FP4 kernels (MXFP4 only; activations quantised to MXFP8)")
     args = ap.parse_args()
 
     dev = torch.device("cuda", 0)
@@ -89,6 +91,8 @@ def main():
     stream = torch.cuda.Stream(dev)
     ws = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)  # 256 MB of split-K scratch
     _lib.lib.petit_set_workspace(C.c_void_p(ws.data_ptr()), C.c_uint64(ws.numel() * 4))
+    if args.native:
+        _lib.lib.petit_enable_native_fp4(1)
     splitks = [int(x) for x in args.splitk.split(",")]
     report = {"device": torch.cuda.get_device_properties(0).gcnArchName, "fmt": args.fmt, "dtype": args.dtype,
               "hbm_peak_gbs": HBM_PEAK, "results": []}
