@@ -4,10 +4,15 @@
 TAG=${1:-r01}
 mkdir -p gpurun_out
 SH="sq8192,sq4096,qkv,gate_up,down"
-python tools/tune.py --shapes $SH --ms 1,2,4,8,16 --fmt nv --dtype bf16 --out gpurun_out/${TAG}_tune_nv_bf16.json > gpurun_out/${TAG}_tune_nv_bf16.log 2>&1
-python tools/tune.py --shapes $SH --ms 1,2,4,8,16 --fmt nv --dtype f16  --out gpurun_out/${TAG}_tune_nv_f16.json  > gpurun_out/${TAG}_tune_nv_f16.log 2>&1
-python tools/tune.py --shapes $SH --ms 1,2,4,8,16 --fmt mx --dtype bf16 --out gpurun_out/${TAG}_tune_mx_bf16.json > gpurun_out/${TAG}_tune_mx_bf16.log 2>&1
-python tools/tune.py --shapes $SH --ms 1,2,4,8,16 --fmt mx --dtype f16  --out gpurun_out/${TAG}_tune_mx_f16.json  > gpurun_out/${TAG}_tune_mx_f16.log 2>&1
-python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 64,128,512 --fmt nv --dtype bf16 --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_nv_bf16.json > gpurun_out/${TAG}_tune_bigm_nv_bf16.log 2>&1
-python tools/tune.py --shapes sq8192,gate_up --ms 128,512 --fmt mx --dtype bf16 --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_mx_bf16.json > gpurun_out/${TAG}_tune_bigm_mx_bf16.log 2>&1
-for f in nv_bf16 nv_f16 mx_bf16 mx_f16 bigm_nv_bf16 bigm_mx_bf16; do echo "== $f"; grep -v amdgpu.ids gpurun_out/${TAG}_tune_$f.log | grep best | cut -c1-175; done
+for fam in "nv bf16" "nv f16" "mx bf16" "mx f16"; do
+  set -- $fam
+  python tools/tune.py --shapes $SH --ms 1,2,4,8,16 --fmt $1 --dtype $2 --out gpurun_out/${TAG}_tune_$1_$2.json > gpurun_out/${TAG}_tune_$1_$2.log 2>&1
+  python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 32,64,128,256 --fmt $1 --dtype $2 --rotate-mb 640 --out gpurun_out/${TAG}_tune_midm_$1_$2.json > gpurun_out/${TAG}_tune_midm_$1_$2.log 2>&1
+done
+# M = 512 (BASELINE config 5): dequant kernels and the vendor 16-bit GEMM on the same shapes
+python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512 --fmt nv --dtype bf16 --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_nv_bf16.json > gpurun_out/${TAG}_tune_bigm_nv_bf16.log 2>&1
+python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512 --fmt nv --dtype f16 --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_nv_f16.json > gpurun_out/${TAG}_tune_bigm_nv_f16.log 2>&1
+python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512 --fmt mx --dtype bf16 --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_mx_bf16.json > gpurun_out/${TAG}_tune_bigm_mx_bf16.log 2>&1
+# the opt-in native-FP4 kernels (MXFP4 weights x MXFP8-quantised activations) next to them
+python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512,2048 --fmt mx --dtype bf16 --native --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_native_mx_bf16.json > gpurun_out/${TAG}_tune_native_mx_bf16.log 2>&1
+for f in gpurun_out/${TAG}_tune_*.log; do echo "== $f"; grep -v amdgpu.ids $f | grep best | cut -c1-200; done

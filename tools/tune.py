@@ -49,8 +49,11 @@ def time_graph(fn_launch, launches: int, reps: int, stream) -> list:
         with torch.cuda.graph(g, stream=stream):
             for i in range(launches):
                 fn_launch(i)
-        g.replay()
-        stream.synchronize()
+        # warm-up: replay for >= 20 ms so clocks are in steady state (DVFS ramp, see bench.py)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.02:
+            g.replay()
+            stream.synchronize()
         out = []
         for _ in range(reps):
             e0 = torch.cuda.Event(enable_timing=True)
