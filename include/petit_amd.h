@@ -95,6 +95,32 @@ int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b
                                const petit_solution_hints *hints,
                                uint64_t solution_id, void *stream);
 
+/*
+ * The same two GEMMs with a fused epilogue (no counterpart in the reference,
+ * whose callers add the bias in a separate torch op after the kernel has already rounded to 16 bit):
+ *   c[m][n] = round16( acc[m][n] * (*global_scale) + bias[n] )
+ * bias: device pointer to n elements of c's type (hints->c_type), 8-byte aligned, or NULL.
+ * epilogue == NULL or {NULL, 0, 0} is exactly the plain call.  `activation` is reserved: anything
+ * but PETIT_ACTIVATION_NONE returns PETIT_ERROR_BAD_ARGUMENT.
+ */
+#define PETIT_ACTIVATION_NONE 0
+typedef struct petit_epilogue {
+    const void *bias;
+    int32_t activation;
+    int32_t reserved;
+} petit_epilogue;
+
+int petit_gemm_fp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b,
+                                const unsigned *scales, const float *global_scale,
+                                unsigned m, unsigned n, unsigned k,
+                                const petit_solution_hints *hints, uint64_t solution_id,
+                                const petit_epilogue *epilogue, void *stream);
+int petit_gemm_mxfp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b,
+                                  const unsigned *scales, const float *global_scale,
+                                  unsigned m, unsigned n, unsigned k,
+                                  const petit_solution_hints *hints, uint64_t solution_id,
+                                  const petit_epilogue *epilogue, void *stream);
+
 /* Enumerate the kernels that can run (hints, m, n, k).  Count-then-fill: call
  * with sols == NULL to get *n_sols, then again with a buffer of that size.
  *   replaces fp4::GemmGetSolutions     quantization/gemm.h:132-133
@@ -138,6 +164,18 @@ int petit_repack_nvfp4_scales(unsigned *out_scales, const unsigned *scales,
                               unsigned in_chan, unsigned out_chan, void *stream);
 int petit_repack_mxfp4_scales(unsigned *out_scales, const unsigned *scales,
                               unsigned in_chan, unsigned out_chan, void *stream);
+
+/*
+ * Offline twins of the three repack entry points for HOST memory: convert a checkpoint's native
+ * NVFP4 / MXFP4 tensors into the packed layout on the CPU, so load-time GPU repack becomes
+ * optional (the reference has no counterpart -- its repack exists only as
+ * GPU kernels, quantization_utils.cu:208-304).  Same shapes, same bytes out as the device
+ * versions (tests compare them bit for bit); out of place only.  These are NOT a CPU fallback of
+ * the GEMM: the packed tensors are consumed by the GPU kernels alone.
+ */
+int petit_repack_nvfp4_weights_host(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan);
+int petit_repack_nvfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan);
+int petit_repack_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan);
 
 /*
  * Optional fp32 scratch for kernels that split K across workgroups.  The

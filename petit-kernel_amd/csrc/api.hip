@@ -191,7 +191,9 @@ bool native_enabled() {
 
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
               const float *global_scale, unsigned m, unsigned n, unsigned k,
-              const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
+              const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue, void *stream) {
+    if (epilogue && (epilogue->activation != PETIT_ACTIVATION_NONE || epilogue->reserved != 0))
+        return kErrBadArgument; // only the bias is implemented; reject what a newer caller might ask for
     if (m == 0 || n == 0 || k == 0)
         return kOk; // gemm_fp4_fp16_grid.cc:42-44
     if (!hints || !c || !a || !b || !scales || !global_scale)
@@ -237,6 +239,7 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     GemmArgs args{};
     args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
     args.m = m, args.n = n, args.k = k;
+    args.bias = epilogue ? epilogue->bias : nullptr;
     if (entry->shape.am == kNativeAm) {
         Workspace &ws = g_workspace[current_device()];
         if (ws.ptr.load() == nullptr || ws.bytes.load() < native_ws_bytes(m, k))
@@ -267,14 +270,28 @@ extern "C" {
 int petit_gemm_fp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                              const float *global_scale, unsigned m, unsigned n, unsigned k,
                              const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
-    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, stream);
+    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, stream);
+}
+
+int petit_gemm_fp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+                                const float *global_scale, unsigned m, unsigned n, unsigned k,
+                                const petit_solution_hints *hints, uint64_t solution_id,
+                                const petit_epilogue *epilogue, void *stream) {
+    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                const float *global_scale, unsigned m, unsigned n, unsigned k,
                                const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
     // the reference forces element_b = MxFp4 into the id (gemm_fp4_fp16_grid.cc:79-95)
-    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, stream);
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, stream);
+}
+
+int petit_gemm_mxfp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+                                  const float *global_scale, unsigned m, unsigned n, unsigned k,
+                                  const petit_solution_hints *hints, uint64_t solution_id,
+                                  const petit_epilogue *epilogue, void *stream) {
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, stream);
 }
 
 int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
@@ -333,6 +350,22 @@ int petit_repack_mxfp4_scales(unsigned *out_scales, const unsigned *scales, unsi
     if ((!out_scales || !scales) && in_chan && out_chan)
         return kErrBadArgument;
     return repack_mxscales(out_scales, scales, in_chan, out_chan, (hipStream_t)stream);
+}
+
+int petit_repack_nvfp4_weights_host(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan) {
+    if ((!output || !input || output == input) && in_chan && out_chan)
+        return kErrBadArgument;
+    return repack_weights_host(output, input, in_chan, out_chan);
+}
+int petit_repack_nvfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan) {
+    if ((!out_scales || !scales || out_scales == scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return repack_nvscales_host(out_scales, scales, in_chan, out_chan);
+}
+int petit_repack_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan) {
+    if ((!out_scales || !scales || out_scales == scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return repack_mxscales_host(out_scales, scales, in_chan, out_chan);
 }
 
 int petit_set_workspace(void *device_ptr, uint64_t bytes) {

@@ -197,6 +197,30 @@ __device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi) {
     return __builtin_bit_cast(unsigned, q);
 }
 
+// The epilogue of every kernel: 4 consecutive n of one output row, x global scale (+ bias[n..n+3]
+// when the caller fused one, petit_epilogue in include/petit_amd.h), ONE round-to-nearest-even to
+// the 16-bit output type (qgemm.cuh:95-192 in the reference, which has no bias).
+template <class AT> __device__ __forceinline__ uint2 finish4(const f32x4 v, const float gs, const void *bias, const unsigned n) {
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+        const uint2 raw = *reinterpret_cast<const uint2 *>((const char *)bias + (size_t)n * 2);
+        const unsigned w0 = raw.x, w1 = raw.y; // named scalars: see the bit_cast note in DESIGN.md section 9
+        if constexpr (AT::kType == kDataTypeBf16) {
+            const unsigned b0 = w0 << 16, b1 = w0 & 0xffff0000u, b2 = w1 << 16, b3 = w1 & 0xffff0000u;
+            b[0] = __builtin_bit_cast(float, b0), b[1] = __builtin_bit_cast(float, b1);
+            b[2] = __builtin_bit_cast(float, b2), b[3] = __builtin_bit_cast(float, b3);
+        } else {
+            const f16x2 h0 = __builtin_bit_cast(f16x2, w0), h1 = __builtin_bit_cast(f16x2, w1);
+            const _Float16 e0 = h0[0], e1 = h0[1], e2 = h1[0], e3 = h1[1];
+            b[0] = (float)e0, b[1] = (float)e1, b[2] = (float)e2, b[3] = (float)e3;
+        }
+    }
+    uint2 o;
+    o.x = pack2(AT{}, __builtin_fmaf(v[0], gs, b[0]), __builtin_fmaf(v[1], gs, b[1]));
+    o.y = pack2(AT{}, __builtin_fmaf(v[2], gs, b[2]), __builtin_fmaf(v[3], gs, b[3]));
+    return o;
+}
+
 // Scale record of one span for one n-tile: KS*2 bytes (NV) / KS bytes (MX).
 template <int FMT, int KS> struct ScaleRec {
     static constexpr int kBytes = (FMT == kFmtNv ? 2 : 1) * KS;
@@ -666,10 +690,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         if (m >= p.m || ntile >= ntiles)
             return;
         if (gridDim.z == 1) {
-            uint2 o;
-            o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
-            o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
-            *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = o;
+            *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
         } else {
             float *slab = p.workspace + ((size_t)blockIdx.z * p.m + m) * p.n + n;
             *reinterpret_cast<f32x4 *>(slab) = v;
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 // Second pass of the cross-workgroup split-K: sum the fp32 slabs in a fixed
 // order (deterministic), apply the global scale, round once.
 template <class AT>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(void *c, const float *ws, const float *gs_ptr,
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(void *c, const float *ws, const float *gs_ptr, const void *bias,
                                                             unsigned m, unsigned n, unsigned parts) {
     const size_t total4 = (size_t)m * n / 4;
     const float gs = *gs_ptr;
@@ -727,10 +748,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(void *c, const float
         f32x4 v = reinterpret_cast<const f32x4 *>(ws)[i];
         for (unsigned q = 1; q < parts; ++q)
             v += reinterpret_cast<const f32x4 *>(ws + (size_t)q * m * n)[i];
-        uint2 o;
-        o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
-        o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
-        reinterpret_cast<uint2 *>(c)[i] = o;
+        reinterpret_cast<uint2 *>(c)[i] = finish4<AT>(v, gs, bias, (unsigned)((i * 4) % n));
     }
 }
 

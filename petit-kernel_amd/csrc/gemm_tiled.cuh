@@ -202,10 +202,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
             const unsigned n = (nt0 + nt) * 16 + g * 4;
             if (m < p.m && (unsigned)nt < valid_nt) {
                 const f32x4 v = acc[mt][nt];
-                uint2 o;
-                o.x = pack2(AT{}, v[0] * gs, v[1] * gs);
-                o.y = pack2(AT{}, v[2] * gs, v[3] * gs);
-                *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = o;
+                *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
             }
         }
 }

@@ -37,6 +37,7 @@ struct GemmArgs {
     const void *w;      // packed weights (layout.h)
     const void *s;      // packed scales  (layout.h)
     const float *gs;    // device pointer, one float
+    const void *bias;   // optional fused epilogue: [n] in c's dtype, added before the single rounding; may be null
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
     unsigned *counters; // split-K arrival tickets (may be null when splitk == 1)
     unsigned m, n, k;
@@ -47,5 +48,8 @@ struct GemmArgs {
 int repack_weights(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
 int repack_nvscales(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
 int repack_mxscales(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
+int repack_weights_host(void *out, const void *in, unsigned k, unsigned n);
+int repack_nvscales_host(void *out, const void *in, unsigned k, unsigned n);
+int repack_mxscales_host(void *out, const void *in, unsigned k, unsigned n);
 
 } // namespace petit_amd

@@ -32,8 +32,17 @@ class SolutionHints(C.Structure):
                 ("require_high_precision", C.c_int32)]
 
 
+class Epilogue(C.Structure):
+    """petit_epilogue (include/petit_amd.h)."""
+    _fields_ = [("bias", C.c_void_p), ("activation", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/petit_amd.h declares, with its signature
 _SIGNATURES = {
+    "petit_gemm_fp4_fp16_grid_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
+                                    [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p]),
+    "petit_gemm_mxfp4_fp16_grid_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
+                                      [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p]),
     "petit_gemm_fp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
                                  [C.POINTER(SolutionHints), C.c_uint64, C.c_void_p]),
     "petit_gemm_mxfp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
@@ -44,6 +53,9 @@ _SIGNATURES = {
     "petit_repack_nvfp4_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "petit_repack_nvfp4_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "petit_repack_mxfp4_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "petit_repack_nvfp4_weights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_repack_nvfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_repack_mxfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
     "petit_set_workspace": (C.c_int, [C.c_void_p, C.c_uint64]),
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
     "petit_enable_native_fp4": (C.c_int, [C.c_int]),

@@ -142,7 +142,7 @@ def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torc
     return out
 
 
-def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id) -> torch.Tensor:
+def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None) -> torch.Tensor:
     if A.dtype != torch.bfloat16 and A.dtype != torch.float16:
         raise RuntimeError("A must be bfloat16 or float16.")
     # Checks the reference leaves out but whose
@@ -159,10 +159,20 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id) 
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
     sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
-    fn = _lib.lib.petit_gemm_fp4_fp16_grid if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
-    with torch.cuda.device(A.device):
-        err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
-                 C.byref(hints), C.c_uint64(sid), _stream(A))
+    if bias is None:
+        fn = _lib.lib.petit_gemm_fp4_fp16_grid if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
+        with torch.cuda.device(A.device):
+            err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
+                     C.byref(hints), C.c_uint64(sid), _stream(A))
+    else:
+        # fused epilogue (include/petit_amd.h, petit_epilogue): c = round16(acc * gs + bias[n])
+        _check(bias.is_cuda and bias.device == A.device and bias.dtype == A.dtype and bias.is_contiguous() and
+               bias.numel() == size_n, "bias must be a contiguous [size_n] tensor of A's dtype on A's device")
+        epi = _lib.Epilogue(bias.data_ptr(), 0, 0)
+        fn = _lib.lib.petit_gemm_fp4_fp16_grid_ex if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid_ex
+        with torch.cuda.device(A.device):
+            err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
+                     C.byref(hints), C.c_uint64(sid), C.byref(epi), _stream(A))
     if err == _lib.PETIT_ERROR_PROBLEM_SHAPE:
         raise RuntimeError(f"Incompatible problem shape (m={size_m}, n={size_n}, k={size_k})")
     if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
@@ -171,22 +181,22 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id) 
     return c
 
 
-def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id) -> torch.Tensor:
-    """fp4.cc:163-209 (MulNvFp4A16)."""
+def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None) -> torch.Tensor:
+    """fp4.cc:163-209 (MulNvFp4A16); `bias` (optional, not in the reference) is fused into the epilogue."""
     if s.dim() != 2 or s.size(1) == 0 or size_k // s.size(1) != 16:
         raise RuntimeError(f"Only groupsize = 16 is supported. size_k = {size_k}, s.size(1) = {s.size(-1)}")
     _check(s.numel() == size_n * size_k // 16, "s does not hold size_n * size_k / 16 scales")
-    return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id)
+    return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias)
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id) -> torch.Tensor:
-    """fp4.cc:211-260 (MulMxFp4A16)."""
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None) -> torch.Tensor:
+    """fp4.cc:211-260 (MulMxFp4A16); `bias` (optional, not in the reference) is fused into the epilogue."""
     _check(B.size(0) == size_n // _LAYOUT_N, f"B.size(0) = {B.size(0)} is not size_n / 16 = {size_n // _LAYOUT_N}")
     _check(B.size(1) == size_k * _LAYOUT_N // _PACK,
            f"B.size(1) = {B.size(1)} is not packed size = {size_k * _LAYOUT_N // _PACK}")
     _check(s.size(0) == size_n // 32, f"s.size(0) = {s.size(0)} is not size_n / 32 = {size_n // 32}")
     _check(s.size(1) == size_k, f"s.size(1) = {s.size(1)} is not size_k = {size_k}")
-    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id)
+    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias)
 
 
 def get_fp4_solutions(*args) -> list:

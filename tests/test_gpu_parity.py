@@ -274,6 +274,64 @@ def test_unknown_solution_and_bad_shapes_raise(pk):
     assert z.shape == (0, 64)                                    # gemm_fp4_fp16_grid.cc:42-44
 
 
+def test_offline_repack_matches_device(pk):
+    """petit_kernel.offline (CPU, checkpoint-side tooling) == the device repack, bit for bit, and the GEMM
+    accepts the CPU-packed tensors."""
+    m, n, k = 3, 96, 1024
+    a, q, s, gs = random_problem("nv", m, n, k, 99, True)
+    qd, sd = torch.from_numpy(q), torch.from_numpy(s).view(torch.float8_e4m3fn)
+    b_cpu = pk.offline.repack_nvfp4_cpu(qd.view(torch.int32), n, k)
+    s_cpu = pk.offline.process_nvfp4_scales_cpu(sd, n, k)
+    b_dev = pk.repack_nvfp4(qd.to(DEV).view(torch.int32), n, k)
+    s_dev = pk.process_nvfp4_scales(sd.to(DEV), n, k)
+    assert torch.equal(b_cpu, b_dev.cpu()) and torch.equal(s_cpu.view(torch.uint8), s_dev.cpu().view(torch.uint8))
+    mx = np.random.default_rng(5).integers(100, 150, (n, k // 32), dtype=np.uint8)
+    assert torch.equal(pk.offline.process_mxfp4_scales_cpu(torch.from_numpy(mx), n, k),
+                       pk.process_mxfp4_scales(torch.from_numpy(mx).to(DEV), n, k).cpu())
+    c = pk.mul_nvfp4_a16(from_bits(a, torch.bfloat16).to(DEV), b_cpu.to(DEV), s_cpu.to(DEV),
+                         torch.tensor([gs], dtype=torch.float32, device=DEV), m, n, k, -1)
+    check_gemm(bits(c), oracle_ref("nv", a, True, q, s, gs), True)
+
+
+@pytest.mark.parametrize("m,n,k,splitk", [(1, 256, 2048, 1), (16, 96, 1024, 1), (40, 64, 3072, 1), (130, 128, 1024, 1), (3, 64, 4096, 2)])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+def test_fused_bias_epilogue(pk, kind, is_bf16, m, n, k, splitk):
+    """c = round16(acc * gs + bias[n]) (petit_epilogue): every kernel kind, one rounding; without a bias the
+    _ex entry point is bit-identical to the plain call."""
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    a, q, s, gs = random_problem(kind, m, n, k, 4321 + m + n + k, is_bf16)
+    bias = torch.randn(n, generator=torch.Generator().manual_seed(n)).mul(4.0).to(dtype)
+    ref = oracle_ref(kind, a, is_bf16, q, s, gs).astype(np.float64) + bias.float().numpy().astype(np.float64)[None, :]
+    ad, qd = from_bits(a, dtype).to(DEV), torch.from_numpy(q).to(DEV)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+    if kind == "nv":
+        b, sp = pk.repack_nvfp4(qd.view(torch.int32), n, k), pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+        mul = pk.mul_nvfp4_a16
+    else:
+        b, sp = pk.repack_mxfp4(qd.view(torch.int32), n, k), pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+        mul = pk.mul_mxfp4_a16
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = dtype
+    h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+    sols = pk.ops.get_fp4_solutions(h, m, n, k)
+    ws = None
+    if splitk > 1:
+        ws = torch.empty(splitk * m * n, dtype=torch.float32, device=DEV)
+        pk.ops.set_workspace(ws)
+        sols = [(sid & ~(0xF << 60)) | (splitk << 60) for sid in sols if (sid >> 48) & 0xF not in (8, 9)][:6]
+    try:
+        sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
+        for sid in [-1] + list(sols):
+            c = mul(ad, b, sp, gsd, m, n, k, sid, bias=bias.to(DEV))
+            check_gemm(bits(c), ref, is_bf16, sum_abs)
+        plain = mul(ad, b, sp, gsd, m, n, k, -1)
+        zero = mul(ad, b, sp, gsd, m, n, k, -1, bias=torch.zeros(n, dtype=dtype, device=DEV))
+        assert torch.equal(plain.view(torch.int16), zero.view(torch.int16))
+    finally:
+        if ws is not None:
+            pk.ops.set_workspace(None)
+
+
 # --- BASELINE.json full sizes: oracle on the whole problem + size-independent properties --
 
 @pytest.mark.parametrize("m", [1, 16])

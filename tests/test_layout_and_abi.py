@@ -177,3 +177,54 @@ def test_python_layer_argument_checks():
     with pytest.raises(RuntimeError, match="Only groupsize = 16 is supported"):
         petit_kernel.mul_nvfp4_a16(a.bfloat16(), qw, s, torch.ones(1), 1, 64, 512, -1)
     assert [d.value for d in petit_kernel.DataType] == [0, 1, 2, 3, 4, 5, 6]  # __init__.py:8-15
+
+
+# --- offline (host-memory) repack: SURVEY.md section 8f-4 ---------------------------------------
+
+@pytest.mark.parametrize("n,k", [(16, 256), (64, 256), (128, 512), (96, 768), (256, 1024), (32, 2048)])
+def test_offline_repack_matches_the_layout_model(n, k):
+    """The C-ABI host twins of the repack entry points produce exactly the packed layout (no GPU)."""
+    import petit_kernel
+    rng = np.random.default_rng(n * 7 + k)
+    q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+    s = rng.integers(0, 256, (n, k // 16), dtype=np.uint8)
+    mx = rng.integers(0, 256, (n, k // 32), dtype=np.uint8)
+    b = petit_kernel.offline.repack_nvfp4_cpu(torch.from_numpy(q).view(torch.int32), n, k)
+    assert b.shape == (n // 16, 2 * k) and b.dtype == torch.int32 and not b.is_cuda
+    assert np.array_equal(b.numpy().view(np.uint32).ravel(), LY.pack_weights(q.view(np.uint32).reshape(n, k // 8)))
+    sp = petit_kernel.offline.process_nvfp4_scales_cpu(torch.from_numpy(s).view(torch.float8_e4m3fn), n, k)
+    assert sp.shape == (n, k // 16) and sp.dtype == torch.float8_e4m3fn
+    assert np.array_equal(sp.view(torch.uint8).numpy().ravel(), LY.pack_nvscales(s, k))
+    if n % 32 == 0:
+        mp = petit_kernel.offline.process_mxfp4_scales_cpu(torch.from_numpy(mx), n, k)
+        assert mp.shape == (n // 32, k) and mp.dtype == torch.uint8
+        assert np.array_equal(mp.numpy().ravel(), LY.pack_mxscales(mx, k))
+
+
+def test_offline_repack_argument_checks():
+    import petit_kernel
+    q = torch.zeros((16, 32), dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="size_k = 200 is not divisible"):
+        petit_kernel.offline.repack_nvfp4_cpu(q, 16, 200)
+    with pytest.raises(RuntimeError, match="qw must be"):
+        petit_kernel.offline.repack_nvfp4_cpu(q, 32, 256)
+    with pytest.raises(RuntimeError, match="not divisible by 32"):
+        petit_kernel.offline.process_mxfp4_scales_cpu(torch.zeros((16, 8), dtype=torch.uint8), 16, 256)
+    from petit_kernel import _lib
+    buf = (C.c_uint * 16)()
+    assert _lib.lib.petit_repack_nvfp4_weights_host(buf, buf, 128, 16) == 4      # in place: bad argument
+    assert _lib.lib.petit_repack_nvfp4_weights_host(buf, None, 128, 16) == 4
+    assert _lib.lib.petit_repack_nvfp4_scales_host(buf, None, 0, 0) == 0         # empty problem
+
+
+def test_epilogue_struct_is_validated_without_a_gpu():
+    """petit_gemm_*_ex rejects epilogue fields it does not implement before touching the device."""
+    from petit_kernel import _lib
+    hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    for fn in (_lib.lib.petit_gemm_fp4_fp16_grid_ex, _lib.lib.petit_gemm_mxfp4_fp16_grid_ex):
+        epi = _lib.Epilogue(None, 1, 0)                       # an activation nobody implements yet
+        assert fn(None, None, None, None, None, 1, 64, 256, C.byref(hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO),
+                  C.byref(epi), None) == _lib.PETIT_ERROR_BAD_ARGUMENT
+        epi = _lib.Epilogue(None, 0, 0)                       # empty problem: ok, nothing enqueued
+        assert fn(None, None, None, None, None, 0, 64, 256, C.byref(hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO),
+                  C.byref(epi), None) == 0
