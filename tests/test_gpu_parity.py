@@ -263,6 +263,37 @@ def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
         check_gemm(c, ref, is_bf16, sum_abs)
 
 
+# The problem sizes of the reference's own GEMM gtest list (fp4/gemm_fp4_fp16_rocm_test.cc:333-425): each
+# TEST_BF16(m, n, k, ...) runs TestGemm(m, lcm(n, 32), lcm(k, 256)); de-duplicated.  Its per-case tile shapes
+# have no meaning here -- every kernel this build enumerates for the problem is run instead.
+REFERENCE_GTEST_PROBLEMS = [
+    (16, 32, 256), (16, 32, 512), (16, 64, 256), (16, 64, 512), (16, 128, 256), (32, 32, 256), (32, 32, 512),
+    (32, 64, 256), (32, 64, 512), (32, 128, 256), (64, 32, 256), (64, 64, 256), (64, 96, 256), (64, 128, 256),
+    (80, 128, 256), (96, 64, 256), (96, 96, 256), (128, 64, 256), (128, 128, 256), (128, 192, 256), (128, 256, 256),
+    (160, 64, 256), (160, 128, 256), (160, 192, 256), (160, 256, 256), (192, 128, 256), (192, 192, 256),
+    (192, 256, 256), (224, 128, 256), (224, 192, 256), (224, 256, 256), (256, 128, 256), (256, 192, 256),
+    (256, 256, 256),
+    (32, 32, 768), (32, 32, 1024), (256, 256, 512), (256, 256, 768), (256, 256, 1024),   # the two Pipeline_* loops (:383-403)
+]
+
+
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+def test_reference_gtest_problem_list(pk, kind, is_bf16):
+    """Same bound as the reference's gtest (max(1e-2, 1 %), :36,53), on its whole problem list, every kernel."""
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+    ran = 0
+    for (m, n, k) in REFERENCE_GTEST_PROBLEMS:
+        a, q, s, gs = random_problem(kind, m, n, k, 31 * m + 7 * n + k, is_bf16)
+        ref = oracle_ref(kind, a, is_bf16, q, s, gs)
+        sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
+        for sid in [-1] + list(pk.ops.get_fp4_solutions(h, m, n, k)):
+            check_gemm(run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid), ref, is_bf16, sum_abs)
+            ran += 1
+    assert ran >= 3 * len(REFERENCE_GTEST_PROBLEMS)
+
+
 def test_unknown_solution_and_bad_shapes_raise(pk):
     a, q, s, gs = random_problem("nv", 1, 64, 256, 5, True)
     with pytest.raises(RuntimeError, match="No kernel implementation for solution_id=4660"):
