@@ -109,7 +109,7 @@ template <class AT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct Nati
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmArgs p, const unsigned char *ws) {
+__global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const GemmArgs p, const unsigned char *ws) {
     using AT = typename Cfg::AT;
     constexpr int KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
     constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;
@@ -151,20 +151,15 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
     const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * p.k, rows * p.k);
     const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + (size_t)p.m * p.k + (size_t)m0 * (p.k / 32), rows * (p.k / 32));
 
-    unsigned w_voff[NTW], s_voff[NTW];
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + nt * w_row_bytes : kOob;
-        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + nt * s_row_bytes : kOob;
-    }
-    // staging: data unit u = tid + i*kThreads -> row u/8, unit u%8; scale dword: thread t < BM -> row t
-    unsigned a_g_voff[UPT], a_l_idx[UPT];
-#pragma unroll
-    for (int i = 0; i < UPT; ++i) {
-        const unsigned u = tid + i * Cfg::kThreads, row = u >> 3, col = u & 7u;
-        a_g_voff[i] = row * p.k + col * 16;
-        a_l_idx[i] = row * Cfg::kRowU4 + col;
-    }
+    // Per-lane offsets are ONE VGPR each; everything that varies with the n-tile, the k-step or the
+    // staging unit rides in the SGPR offset, which gfx950 includes in the buffer range check (probed,
+    // tools/probes): n-tiles beyond valid_nt and rows beyond M still read as zeros.  (The streaming
+    // kernel keeps validity in the VGPR offset; here 12 VGPRs decide between one and two waves per SIMD.)
+    const unsigned w_voff = lane * 16, s_voff = lane * kRecBytes;
+    // staging: data unit u = tid + i*kThreads -> row u/8 = tid/8 + i*kThreads/8, unit u%8 = tid%8
+    const unsigned a_g_voff = (tid >> 3) * p.k + (tid & 7u) * 16;
+    const unsigned a_l_idx = (tid >> 3) * Cfg::kRowU4 + (tid & 7u);
+    const unsigned a_unit_rows = Cfg::kThreads / 8; // rows between a thread's consecutive units
     const bool has_scale_row = tid < (unsigned)Cfg::BM;
     const unsigned qs_voff = has_scale_row ? tid * (p.k / 32) : kOob;
     unsigned *const smem_u32 = reinterpret_cast<unsigned *>(smem);
@@ -179,14 +174,14 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
     auto load_stage = [&](unsigned kt) {
 #pragma unroll
         for (int i = 0; i < UPT; ++i)
-            astage[i] = buf_load16(qa_rsrc, a_g_voff[i], kt * 128, kAuxDefault);
+            astage[i] = buf_load16(qa_rsrc, a_g_voff, i * a_unit_rows * p.k + kt * 128, kAuxDefault);
         sstage = __builtin_amdgcn_raw_buffer_load_b32(qs_rsrc, qs_voff, kt * 4, 0);
     };
     auto store_stage = [&](unsigned buf) {
         u32x4 *const dst = smem + buf * Cfg::kBufU4;
 #pragma unroll
         for (int i = 0; i < UPT; ++i)
-            dst[a_l_idx[i]] = astage[i];
+            dst[a_l_idx + i * a_unit_rows * Cfg::kRowU4] = astage[i];
         smem_u32[buf ? qs_l_idx1 : qs_l_idx0] = sstage;
     };
 
@@ -194,24 +189,19 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
     ScaleRec<kFmtMx, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
-        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[nt], 0u);
+        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, nt * s_row_bytes);
     u32x4 wring[D][NTW];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], i * kTileBytes, kAuxDefault);
+            wring[i][nt] = buf_load16(w_rsrc, w_voff, nt * w_row_bytes + i * kTileBytes, kAuxDefault);
     store_stage(0);
     __syncthreads();
 
     auto span_body = [&](const unsigned sp, auto last_c) {
         constexpr bool kLast = decltype(last_c)::value;
         const unsigned kt0 = sp * KS;
-        if constexpr (!kLast) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-                srec_next[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[nt], (sp + 1) * 64 * kRecBytes);
-        }
         static_for<0, KS>([&](auto t_c) {
             constexpr int T = decltype(t_c)::value;
             constexpr int SLOT = T % D;
@@ -223,6 +213,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
             const unsigned char *const a_cur_bytes = reinterpret_cast<const unsigned char *>(a_cur);
             if constexpr (kNextA)
                 load_stage(kt + 1);
+            if constexpr (!kLast && T == KS - 1) { // next span's scale records: one step ahead is enough
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    srec_next[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, nt * s_row_bytes + (sp + 1) * 64 * kRecBytes);
+            }
             // weights: the lane's uint4 IS the FP4 operand; its scale is byte T of the span record
             i32x8 wop[NTW];
 #pragma unroll
@@ -233,19 +228,53 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_native_kernel(const GemmAr
             if constexpr (kRefill) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxDefault);
+                    wring[SLOT][nt] = buf_load16(w_rsrc, w_voff, nt * w_row_bytes + (kt + D) * kTileBytes, kAuxDefault);
             }
+            // the step's global loads are requested before anything else (hipcc otherwise sinks them
+            // next to their LDS stores at the end of the step and exposes the whole HBM/L2 latency).
+            // Not with 128 accumulator registers: holding the loads across the step (and the second
+            // fragment set below) pushes the kernel past 256 VGPRs = one wave per SIMD, measured
+            // 6-8 % slower at M = 2048 than letting the second wave hide the latency.
+            constexpr bool kPrefetch = true;
+            if constexpr (kPrefetch)
+                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kPrefetch) {
+                // activation fragments: m-tile mt+1 is read from LDS while the MFMAs of m-tile mt run
+                u32x4 flo[2], fhi[2];
+                int fsc[2];
+                auto read_frag = [&](int mt, int slot) {
+                    flo[slot] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4];
+                    fhi[slot] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + 1];
+                    fsc[slot] = (int)a_cur_bytes[a_scale_byte + mt * 16 * Cfg::kRowU4 * 16];
+                };
+                read_frag(0, 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const u32x4 lo = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4];
-                const u32x4 hi = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + 1];
-                const int ascale = (int)a_cur_bytes[a_scale_byte + mt * 16 * Cfg::kRowU4 * 16];
-                const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (mt + 1 < MT)
+                        read_frag(mt + 1, (mt + 1) & 1);
+                    const u32x4 lo = flo[mt & 1], hi = fhi[mt & 1];
+                    const int ascale = fsc[mt & 1];
+                    const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-                        wop[nt], aop, acc[mt][nt], 4 /* A = FP4 */, 0 /* B = FP8 e4m3 */, T % 4,
-                        (int)srec[nt].d[T / 4], 0, ascale);
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            wop[nt], aop, acc[mt][nt], 4 /* A = FP4 */, 0 /* B = FP8 e4m3 */, T % 4,
+                            (int)srec[nt].d[T / 4], 0, ascale);
+                    __builtin_amdgcn_sched_barrier(0); // keep the prefetch one m-tile ahead, no further
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x4 lo = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4];
+                    const u32x4 hi = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + 1];
+                    const int ascale = (int)a_cur_bytes[a_scale_byte + mt * 16 * Cfg::kRowU4 * 16];
+                    const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            wop[nt], aop, acc[mt][nt], 4 /* A = FP4 */, 0 /* B = FP8 e4m3 */, T % 4,
+                            (int)srec[nt].d[T / 4], 0, ascale);
+                }
             }
             if constexpr (kNextA) {
                 store_stage(cur ^ 1u);
