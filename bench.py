@@ -104,11 +104,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; more ranks than GPUs (only useful to smoke-test this flow on a 1-GPU box) wrap around
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm; there is no data-path collective, it only carries the barrier and the
+        # max-over-ranks of the timings.  $PETIT_BENCH_DIST_BACKEND=gloo lets two ranks share one GPU in a smoke run.
+        backend = os.environ.get("PETIT_BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import petit_kernel  # fails loudly when libpetit_amd.so is missing
 
