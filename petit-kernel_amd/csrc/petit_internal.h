@@ -39,7 +39,6 @@ struct GemmArgs {
     const float *gs;    // device pointer, one float
     const void *bias;   // optional fused epilogue: [n] in c's dtype, added before the single rounding; may be null
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
-    unsigned *counters; // split-K arrival tickets (may be null when splitk == 1)
     unsigned m, n, k;
     unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))
 };
