@@ -9,9 +9,13 @@ Tolerances
     (fp4/gemm_fp4_fp16_rocm_test.cc:36,53) and BASELINE.json's "within 1e-2 rel-err"; the
     reference's pytest uses the looser rtol = atol = 2e-2 (tests/ops/test_fp4_gemm_quark.py:54).
 """
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
+
+ROOT = Path(__file__).resolve().parent.parent
 
 from oracle import cdna4_layout as LY
 from oracle import oracle as O
@@ -303,6 +307,31 @@ def test_unknown_solution_and_bad_shapes_raise(pk):
                          torch.zeros((64, 16), dtype=torch.float8_e4m3fn, device=DEV),
                          torch.ones(1, device=DEV), 0, 64, 256, -1)
     assert z.shape == (0, 64)                                    # gemm_fp4_fp16_grid.cc:42-44
+
+
+@pytest.mark.parametrize("kind,is_bf16,m,n,k", [("nv", True, 5, 96, 1024), ("mx", True, 33, 64, 512), ("nv", False, 1, 128, 2048)])
+def test_cxx_api_end_to_end(pk, tmp_path, kind, is_bf16, m, n, k):
+    """A C++ program written against the reference's namespace API (examples/cxx_gemm.cc, include/causalflow/petit/gemm.h)
+    repacks and multiplies on the GPU; its output must match the oracle like the Python path does."""
+    import struct
+    import subprocess
+    from petit_kernel import _lib
+    a, q, s, gs = random_problem(kind, m, n, k, 2024 + m + n + k, is_bf16)
+    prob = tmp_path / "problem.bin"
+    with open(prob, "wb") as f:
+        f.write(struct.pack("<5If", 0 if kind == "nv" else 1, int(is_bf16), m, n, k, gs))
+        f.write(np.ascontiguousarray(a).tobytes())
+        f.write(np.ascontiguousarray(q).tobytes())
+        f.write(np.ascontiguousarray(s).tobytes())
+    exe = tmp_path / "cxx_gemm"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", str(ROOT / "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    str(ROOT / "examples/cxx_gemm.cc"), str(_lib.LIB_PATH), f"-Wl,-rpath,{_lib.LIB_PATH.parent}",
+                    "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([str(exe), str(prob), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    c_bits = np.frombuffer(out.read_bytes(), dtype=np.uint16).reshape(m, n)
+    check_gemm(c_bits, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
 def test_offline_repack_matches_device(pk):
