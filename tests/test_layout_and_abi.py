@@ -228,3 +228,46 @@ def test_epilogue_struct_is_validated_without_a_gpu():
         epi = _lib.Epilogue(None, 0, 0)                       # empty problem: ok, nothing enqueued
         assert fn(None, None, None, None, None, 0, 64, 256, C.byref(hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO),
                   C.byref(epi), None) == 0
+
+
+# --- arch table (csrc/hal.hip): built-in rows and the $PETIT_AMD_TUNE_FILE override ----------------
+
+def _default_solution_in_subprocess(env_extra, a_type, b_type, m, n, k):
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, ctypes as C; sys.path.insert(0, r'%s'); from petit_kernel import _lib; "
+            "h = _lib.SolutionHints(%d, %d, %d, 0); print('%%x' %% _lib.lib.petit_gemm_default_solution(C.byref(h), %d, %d, %d))"
+            % (ROOT / "petit-kernel_amd", a_type, b_type, a_type, m, n, k))
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout
+    return int(out.strip().splitlines()[-1], 16)
+
+
+def test_arch_table_rows_and_tune_file_override(tmp_path):
+    """solution_id = -1 consults the measured table first (every row must name a kernel that exists and fits),
+    and a $PETIT_AMD_TUNE_FILE row written in tools/tune.py's format takes precedence over it."""
+    from petit_kernel import _lib
+    rows = re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}",
+                      (ROOT / "petit-kernel_amd/csrc/tuned_gfx950.inc").read_text())
+    assert len(rows) >= 100
+    for at, bt, n, k, lo, hi, sol in rows:
+        at, bt, n, k, lo, hi, sol = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16)
+        hints = _lib.SolutionHints(at, bt, at, 0)
+        assert (sol >> 32) & 7 != 2, "a native-FP4 kernel must never be a default"
+        for m in {lo, min(hi, lo + 3)}:
+            assert _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k) == sol, (at, bt, n, k, m, hex(sol))
+            assert "unknown" not in _lib.describe_solution(sol)
+    # override: pick some other enumerated kernel for one of the table's shapes
+    at, bt, n, k, lo, hi, sol = rows[0]
+    at, bt, n, k, lo, sol = int(at), int(bt), int(n), int(k), int(lo), int(sol, 16)
+    hints = _lib.SolutionHints(at, bt, at, 0)
+    cnt = C.c_uint(0)
+    assert _lib.lib.petit_gemm_get_solutions(C.byref(hints), lo, n, k, None, C.byref(cnt)) == 0
+    ids = (C.c_uint64 * cnt.value)()
+    assert _lib.lib.petit_gemm_get_solutions(C.byref(hints), lo, n, k, ids, C.byref(cnt)) == 0
+    other = next(i for i in ids if i != sol)
+    tune = tmp_path / "tune.txt"
+    tune.write_text(f"# a_type b_type n k m_lo m_hi solution\n{at} {bt} {n} {k} {lo} {lo} {other:x}\n")
+    assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune)}, at, bt, lo, n, k) == other
+    assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": ""}, at, bt, lo, n, k) == sol
