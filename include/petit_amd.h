@@ -100,10 +100,16 @@ int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b
  * whose callers add the bias in a separate torch op after the kernel has already rounded to 16 bit):
  *   c[m][n] = round16( acc[m][n] * (*global_scale) + bias[n] )
  * bias: device pointer to n elements of c's type (hints->c_type), 8-byte aligned, or NULL.
- * epilogue == NULL or {NULL, 0, 0} is exactly the plain call.  `activation` is reserved: anything
- * but PETIT_ACTIVATION_NONE returns PETIT_ERROR_BAD_ARGUMENT.
+ * epilogue == NULL or {NULL, 0, 0} is exactly the plain call.
+ * activation = PETIT_ACTIVATION_SILU_MUL (the gate_up projection of a gated MLP, vLLM's SiluAndMul fused
+ * in): with y = acc * (*global_scale) + bias, c is [m][n/2] and
+ *   c[m][j] = round16( silu(y[m][j]) * y[m][j + n/2] ),   silu(x) = x / (1 + exp(-x)).
+ * Needs n % 32 == 0 and a kernel with an even number of n-tiles per wave: PETIT_SOLUTION_AUTO picks one;
+ * an explicit id without that property (or with a cross-workgroup K split) returns PETIT_ERROR_KERNEL_SHAPE.
+ * Any other activation value returns PETIT_ERROR_BAD_ARGUMENT.
  */
 #define PETIT_ACTIVATION_NONE 0
+#define PETIT_ACTIVATION_SILU_MUL 1
 typedef struct petit_epilogue {
     const void *bias;
     int32_t activation;

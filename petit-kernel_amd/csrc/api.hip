@@ -91,7 +91,10 @@ uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
 // workgroup count best fills the chip without starving each wave of work.
 // (The reference's heuristic ignores the CU count altogether and leaves half of
 // a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
-const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k) {
+// SiLU-mul epilogue: a wave must hold the gate and the up tile of an output tile -> even n-tiles per wave
+bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0; }
+
+const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k, bool need_pairs = false) {
     // Rules distilled from the MI355X sweeps (profiles/):
     //  * M <= 16: stage the activations through LDS (AM = smallest that holds M);
     //  * what saturates HBM is bytes in flight: as many resident waves as the grid
@@ -110,7 +113,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         unsigned pick_wgs = 0;
         for (int i = 0; i < fam.count; ++i) {
             const SolutionEntry &e = fam.entries[i];
-            if (e.shape.am != kTiledAm || !entry_fits(e, m, k))
+            if (e.shape.am != kTiledAm || !entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
                 continue; // (never the native-FP4 kernels: different accuracy class)
             const unsigned per_wg = e.shape.nt * e.shape.wn;
             const unsigned wgs = ((m + 16 * e.shape.mt - 1) / (16 * e.shape.mt)) * ((ntiles + per_wg - 1) / per_wg);
@@ -130,7 +133,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     double best_score = -1e30;
     for (int i = 0; i < fam.count; ++i) {
         const SolutionEntry &e = fam.entries[i];
-        if (!entry_fits(e, m, k))
+        if (!entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
             continue;
         const StreamShape &s = e.shape;
         if (s.mt != want_mt || s.am == kTiledAm || s.am == kNativeAm)
@@ -154,7 +157,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
             if (entry_fits(fam.entries[i], m, k) && fam.entries[i].shape.am != kTiledAm &&
-                fam.entries[i].shape.am != kNativeAm &&
+                fam.entries[i].shape.am != kNativeAm && (!need_pairs || act_ok(fam.entries[i])) &&
                 (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
     }
@@ -192,8 +195,10 @@ bool native_enabled() {
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
               const float *global_scale, unsigned m, unsigned n, unsigned k,
               const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue, void *stream) {
-    if (epilogue && (epilogue->activation != PETIT_ACTIVATION_NONE || epilogue->reserved != 0))
-        return kErrBadArgument; // only the bias is implemented; reject what a newer caller might ask for
+    if (epilogue && ((epilogue->activation != PETIT_ACTIVATION_NONE && epilogue->activation != PETIT_ACTIVATION_SILU_MUL) ||
+                     epilogue->reserved != 0))
+        return kErrBadArgument; // reject what a newer caller might ask for
+    const bool act = epilogue && epilogue->activation == PETIT_ACTIVATION_SILU_MUL;
     if (m == 0 || n == 0 || k == 0)
         return kOk; // gemm_fp4_fp16_grid.cc:42-44
     if (!hints || !c || !a || !b || !scales || !global_scale)
@@ -204,6 +209,9 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     if (!family_for(hints->a_type, b_type, &fam))
         return kErrKernelShape;
     if (!shape_ok(n, k))
+        return kErrProblemShape;
+    // SiLU-mul: gate / up halves made of whole n-tiles, and one descriptor spans half the matrix
+    if (act && (n % 32 != 0 || (uint64_t)n * k / 2 >= (1ull << 32)))
         return kErrProblemShape;
     // 32-bit buffer offsets inside one n-tile row / activation block
     if ((uint64_t)k * 16 * 4 * 2 >= (1ull << 31) || (uint64_t)k * 64 * 4 >= (1ull << 31))
@@ -217,10 +225,10 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             entry = find_entry(fam, tuned);
             splitk = solution_splitk(tuned);
         }
-        if (entry && !entry_fits(*entry, m, k))
+        if (entry && (!entry_fits(*entry, m, k) || (act && (!act_ok(*entry) || splitk != 1))))
             entry = nullptr;
         if (!entry) {
-            entry = heuristic(fam, m, n, k);
+            entry = heuristic(fam, m, n, k, act);
             splitk = 1;
         }
         if (!entry)
@@ -234,12 +242,15 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         splitk = solution_splitk(solution_id);
         if (splitk == 0)
             return kErrKernelShape;
+        if (act && (!act_ok(*entry) || splitk != 1))
+            return kErrKernelShape; // needs an even number of n-tiles per wave and no cross-workgroup K split
     }
 
     GemmArgs args{};
     args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
     args.m = m, args.n = n, args.k = k;
     args.bias = epilogue ? epilogue->bias : nullptr;
+    args.act = act ? 1u : 0u;
     if (entry->shape.am == kNativeAm) {
         Workspace &ws = g_workspace[current_device()];
         if (ws.ptr.load() == nullptr || ws.bytes.load() < native_ws_bytes(m, k))

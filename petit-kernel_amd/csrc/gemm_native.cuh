@@ -142,11 +142,17 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     const unsigned w_row_bytes = ktiles * kTileBytes;
     const unsigned s_row_bytes = p.k / 2;
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
-    const unsigned nt_base = valid_nt ? nt0 : 0u;
+    // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; gemm_stream.cuh)
+    const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
+    const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        make_rsrc((const char *)p.w + (size_t)nt_base * w_row_bytes, valid_nt * w_row_bytes);
+        make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
     const __amdgpu_buffer_rsrc_t s_rsrc =
-        make_rsrc((const char *)p.s + (size_t)nt_base * s_row_bytes, valid_nt * s_row_bytes);
+        make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
+    // tile nt of this wave, relative to pt0 (scalar: rides in the SGPR offset of every load)
+    auto rel_tile = [&](int nt) -> unsigned {
+        return ((unsigned)nt < valid_nt) ? physical_tile(nt0 + nt, ntiles, p.act) - pt0 : span_tiles; // beyond: out of range
+    };
     // quantised activations and their scales (rows beyond M read as zeros: 0 * 2^-127)
     const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * p.k, rows * p.k);
     const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + (size_t)p.m * p.k + (size_t)m0 * (p.k / 32), rows * (p.k / 32));
@@ -189,13 +195,13 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     ScaleRec<kFmtMx, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
-        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, nt * s_row_bytes);
+        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, rel_tile(nt) * s_row_bytes);
     u32x4 wring[D][NTW];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            wring[i][nt] = buf_load16(w_rsrc, w_voff, nt * w_row_bytes + i * kTileBytes, kAuxDefault);
+            wring[i][nt] = buf_load16(w_rsrc, w_voff, rel_tile(nt) * w_row_bytes + i * kTileBytes, kAuxDefault);
     store_stage(0);
     __syncthreads();
 
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
             if constexpr (!kLast && T == KS - 1) { // next span's scale records: one step ahead is enough
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    srec_next[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, nt * s_row_bytes + (sp + 1) * 64 * kRecBytes);
+                    srec_next[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, rel_tile(nt) * s_row_bytes + (sp + 1) * 64 * kRecBytes);
             }
             // weights: the lane's uint4 IS the FP4 operand; its scale is byte T of the span record
             i32x8 wop[NTW];
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
             if constexpr (kRefill) {
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
-                    wring[SLOT][nt] = buf_load16(w_rsrc, w_voff, nt * w_row_bytes + (kt + D) * kTileBytes, kAuxDefault);
+                    wring[SLOT][nt] = buf_load16(w_rsrc, w_voff, rel_tile(nt) * w_row_bytes + (kt + D) * kTileBytes, kAuxDefault);
             }
             // the step's global loads are requested before anything else (hipcc otherwise sinks them
             // next to their LDS stores at the end of the step and exposes the whole HBM/L2 latency).
@@ -301,6 +307,22 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
             pin_acc(acc[mt][nt]); // every MFMA executes with all 64 lanes, before the divergent stores
 
     const float gs = *p.gs;
+    if (p.act) { // SiLU-mul: tiles (nt, nt + 1) are the gate / up halves of output tile (nt0 + nt) / 2
+        if constexpr (NTW % 2 == 0) {
+            const unsigned n_half = p.n >> 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt += 2) {
+                    const unsigned m = m0 + mt * 16 + r;
+                    const unsigned n = ((nt0 + nt) >> 1) * 16 + g * 4;
+                    if (m < p.m && (unsigned)nt < valid_nt)
+                        *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * n_half + n) * 2) =
+                            finish4_silu_mul<AT>(acc[mt][nt], acc[mt][nt + 1], gs, p.bias, n, n_half);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

@@ -221,6 +221,48 @@ template <class AT> __device__ __forceinline__ uint2 finish4(const f32x4 v, cons
     return o;
 }
 
+// SiLU-mul epilogue (petit_epilogue.activation = 1): `gate` holds 4 consecutive columns j of the first half of
+// the GEMM's N, `up` the same columns of the second half; out[j] = silu(y_gate[j]) * y_up[j], y = acc*gs + bias,
+// rounded once.  bias (if any) spans the full N: gate part at n, up part at n + n_half.
+template <class AT>
+__device__ __forceinline__ uint2 finish4_silu_mul(const f32x4 gate, const f32x4 up, const float gs, const void *bias,
+                                                  const unsigned n, const unsigned n_half) {
+    float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (bias) {
+        auto load4 = [&](unsigned col, float *b) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>((const char *)bias + (size_t)col * 2);
+            const unsigned w0 = raw.x, w1 = raw.y;
+            if constexpr (AT::kType == kDataTypeBf16) {
+                const unsigned b0 = w0 << 16, b1 = w0 & 0xffff0000u, b2 = w1 << 16, b3 = w1 & 0xffff0000u;
+                b[0] = __builtin_bit_cast(float, b0), b[1] = __builtin_bit_cast(float, b1);
+                b[2] = __builtin_bit_cast(float, b2), b[3] = __builtin_bit_cast(float, b3);
+            } else {
+                const f16x2 h0 = __builtin_bit_cast(f16x2, w0), h1 = __builtin_bit_cast(f16x2, w1);
+                const _Float16 e0 = h0[0], e1 = h0[1], e2 = h1[0], e3 = h1[1];
+                b[0] = (float)e0, b[1] = (float)e1, b[2] = (float)e2, b[3] = (float)e3;
+            }
+        };
+        load4(n, bg);
+        load4(n + n_half, bu);
+    }
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float g = __builtin_fmaf(gate[i], gs, bg[i]), u = __builtin_fmaf(up[i], gs, bu[i]);
+        o[i] = g / (1.0f + __expf(-g)) * u;
+    }
+    uint2 r;
+    r.x = pack2(AT{}, o[0], o[1]);
+    r.y = pack2(AT{}, o[2], o[3]);
+    return r;
+}
+
+// Logical n-tile L of a kernel's grid -> physical n-tile of W.  Plain GEMM: identity.  SiLU-mul: consecutive
+// logical tiles (2p, 2p+1) are the gate tile p and the up tile p + ntiles/2, so that one wave (even NT) holds both.
+__device__ __forceinline__ unsigned physical_tile(unsigned l, unsigned ntiles, unsigned act) {
+    return act ? (l >> 1) + (l & 1u) * (ntiles >> 1) : l;
+}
+
 // Scale record of one span for one n-tile: KS*2 bytes (NV) / KS bytes (MX).
 template <int FMT, int KS> struct ScaleRec {
     static constexpr int kBytes = (FMT == kFmtNv ? 2 : 1) * KS;
@@ -371,10 +413,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         const unsigned s_row_bytes = (FMT == kFmtNv) ? p.k : p.k / 2; // one n-tile of scales
         const unsigned rows = min(p.m - m0, (unsigned)(16 * MT));
 
+        // tile offsets relative to the wave's first physical tile (identity mapping: nt; SiLU-mul: gate/up pairs)
+        const unsigned pt0 = physical_tile(nt0, ntiles, p.act);
+        const unsigned span_tiles = p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt; // tiles the descriptor must cover
         const __amdgpu_buffer_rsrc_t w_rsrc =
-            make_rsrc((const char *)p.w + (size_t)nt0 * w_row_bytes, valid_nt * w_row_bytes);
+            make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
         const __amdgpu_buffer_rsrc_t s_rsrc =
-            make_rsrc((const char *)p.s + (size_t)nt0 * s_row_bytes, valid_nt * s_row_bytes);
+            make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
         const __amdgpu_buffer_rsrc_t a_rsrc =
             make_rsrc((const char *)p.a + (size_t)m0 * p.k * 2, rows * p.k * 2);
 
@@ -383,8 +428,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         unsigned w_voff[NT], s_voff[NT], a_voff[MT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + nt * w_row_bytes : kOob;
-            s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + nt * s_row_bytes : kOob;
+            const unsigned rel = physical_tile(nt0 + nt, ntiles, p.act) - pt0;
+            w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
+            s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -696,6 +742,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             *reinterpret_cast<f32x4 *>(slab) = v;
         }
     };
+    // SiLU-mul: logical tiles (inn, inn + 1) are the gate / up halves of output tile ntile / 2 (host guarantees
+    // an even NT, an even N/16 and gridDim.z == 1)
+    auto emit_pair = [&](f32x4 gate, f32x4 up, unsigned iwn, unsigned imt, unsigned inn, unsigned il) {
+        const unsigned m = m0 + imt * 16 + (il & 15u);
+        const unsigned ntile = (blockIdx.x * WN + iwn) * NT + inn;
+        if (m >= p.m || ntile >= ntiles)
+            return;
+        const unsigned n_half = p.n >> 1;
+        const unsigned n = (ntile >> 1) * 16 + (il >> 4) * 4;
+        *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * n_half + n) * 2) =
+            finish4_silu_mul<AT>(gate, up, gs, p.bias, n, n_half);
+    };
 
     f32x4 accs[MT][NT];
 #pragma unroll
@@ -711,11 +769,21 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             }
         }
     if constexpr (WK == 1) {
+        if (p.act) {
+            if constexpr (NT % 2 == 0) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                emit(accs[mt][nt], wn, mt, nt, lane);
+                    for (int nt = 0; nt < NT; nt += 2)
+                        emit_pair(accs[mt][nt], accs[mt][nt + 1], wn, mt, nt, lane);
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    emit(accs[mt][nt], wn, mt, nt, lane);
+        }
     } else {
         constexpr int kItems = Cfg::kRedItems;
         f32x4 *const red = reinterpret_cast<f32x4 *>(smem + WN * WK * Cfg::kALdsU4);
@@ -726,12 +794,24 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 red[wk * kItems + ((wn * MT + mt) * NT + nt) * 64 + lane] = accs[mt][nt];
         __syncthreads();
         for (unsigned item = threadIdx.x; item < (unsigned)kItems; item += Cfg::kThreads) {
+            const unsigned tile = item >> 6;
+            if (p.act && (tile % NT) % 2 != 0)
+                continue; // the up half is consumed together with its gate tile
             f32x4 v = red[item];
 #pragma unroll
             for (int q = 1; q < WK; ++q)
                 v += red[q * kItems + item];
-            const unsigned tile = item >> 6;
-            emit(v, tile / (MT * NT), (tile / NT) % MT, tile % NT, item & 63u);
+            if (p.act) {
+                if constexpr (NT % 2 == 0) {
+                    f32x4 u = red[item + 64];
+#pragma unroll
+                    for (int q = 1; q < WK; ++q)
+                        u += red[q * kItems + item + 64];
+                    emit_pair(v, u, tile / (MT * NT), (tile / NT) % MT, tile % NT, item & 63u);
+                }
+            } else {
+                emit(v, tile / (MT * NT), (tile / NT) % MT, tile % NT, item & 63u);
+            }
         }
     }
 }

@@ -76,18 +76,21 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
 
     // a wave whose n-tiles all fall beyond N still helps staging A and hits the barriers
-    const unsigned nt_base = valid_nt ? nt0 : 0u;
+    // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; gemm_stream.cuh)
+    const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
+    const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        make_rsrc((const char *)p.w + (size_t)nt_base * w_row_bytes, valid_nt * w_row_bytes);
+        make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
     const __amdgpu_buffer_rsrc_t s_rsrc =
-        make_rsrc((const char *)p.s + (size_t)nt_base * s_row_bytes, valid_nt * s_row_bytes);
+        make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc((const char *)p.a + (size_t)m0 * p.k * 2, rows * p.k * 2);
 
     unsigned w_voff[NTW], s_voff[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + nt * w_row_bytes : kOob;
-        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + nt * s_row_bytes : kOob;
+        const unsigned rel = physical_tile(nt0 + nt, ntiles, p.act) - pt0;
+        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
+        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
     }
     // A staging: unit u = tid + i*kThreads -> row u/16, 16-byte column u%16 (a row's 256 B are
     // read by 16 consecutive lanes: full lines)
@@ -194,6 +197,22 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
 
     // --- epilogue: x global scale, one RNE rounding, 8-byte stores
     const float gs = *p.gs;
+    if (p.act) { // SiLU-mul: tiles (nt, nt + 1) are the gate / up halves of output tile (nt0 + nt) / 2
+        if constexpr (NTW % 2 == 0) {
+            const unsigned n_half = p.n >> 1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; nt += 2) {
+                    const unsigned m = m0 + mt * 16 + r;
+                    const unsigned n = ((nt0 + nt) >> 1) * 16 + g * 4;
+                    if (m < p.m && (unsigned)nt < valid_nt)
+                        *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * n_half + n) * 2) =
+                            finish4_silu_mul<AT>(acc[mt][nt], acc[mt][nt + 1], gs, p.bias, n, n_half);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

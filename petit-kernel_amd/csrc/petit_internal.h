@@ -38,6 +38,7 @@ struct GemmArgs {
     const void *s;      // packed scales  (layout.h)
     const float *gs;    // device pointer, one float
     const void *bias;   // optional fused epilogue: [n] in c's dtype, added before the single rounding; may be null
+    unsigned act;       // 0 none; 1 SiLU-mul: c is [m][n/2], c[m][j] = silu(y[m][j]) * y[m][j + n/2]  (y = acc*gs + bias)
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
     unsigned m, n, k;
     unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))

@@ -45,15 +45,18 @@ def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torc
 
 
 def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
-                  size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None) -> torch.Tensor:
-    # `bias` is an extension (keyword-only, default None = the reference's behaviour): [size_n] of a.dtype,
-    # added before the single rounding to 16 bit
-    return ops.mul_nvfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias)
+                  size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None,
+                  activation: str = None) -> torch.Tensor:
+    # `bias` / `activation` are extensions (keyword-only, default None = the reference's behaviour):
+    #   bias       [size_n] of a.dtype, added before the single rounding to 16 bit
+    #   activation "silu_mul": returns [size_m, size_n/2] = silu(y[:, :n/2]) * y[:, n/2:]  (gate_up of a gated MLP)
+    return ops.mul_nvfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def mul_mxfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
-                  size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None) -> torch.Tensor:
-    return ops.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias)
+                  size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None,
+                  activation: str = None) -> torch.Tensor:
+    return ops.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def get_fp4_solutions(size_m: int, size_n: int, size_k: int, a_type, c_type) -> list:

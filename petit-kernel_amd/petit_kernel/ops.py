@@ -142,7 +142,10 @@ def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torc
     return out
 
 
-def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None) -> torch.Tensor:
+_ACTIVATIONS = {None: 0, "none": 0, "silu_mul": 1}   # PETIT_ACTIVATION_* (include/petit_amd.h)
+
+
+def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
     if A.dtype != torch.bfloat16 and A.dtype != torch.float16:
         raise RuntimeError("A must be bfloat16 or float16.")
     # Checks the reference leaves out but whose
@@ -152,23 +155,28 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
     _check(B.is_contiguous() and B.numel() * B.element_size() == size_n * size_k // 2,
            "B does not hold size_n * size_k packed 4-bit weights")
     _check(global_scale.dtype == torch.float32 and global_scale.numel() >= 1, "global_scale must be float32")
-    c = torch.empty((size_m, size_n), dtype=A.dtype, device=A.device)
+    _check(activation in _ACTIVATIONS, f"activation must be one of {sorted(k for k in _ACTIVATIONS if k)} or None")
+    act = _ACTIVATIONS[activation]
+    if act:
+        _check(size_n % 32 == 0, f"silu_mul needs size_n % 32 == 0 (gate / up halves of whole tiles), got {size_n}")
+    c = torch.empty((size_m, size_n // 2 if act else size_n), dtype=A.dtype, device=A.device)
     a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
     b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
     # require_high_precision: the reference turns it on for arch <= gfx90a when
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
     sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
-    if bias is None:
+    if bias is None and not act:
         fn = _lib.lib.petit_gemm_fp4_fp16_grid if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
         with torch.cuda.device(A.device):
             err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
                      C.byref(hints), C.c_uint64(sid), _stream(A))
     else:
-        # fused epilogue (include/petit_amd.h, petit_epilogue): c = round16(acc * gs + bias[n])
-        _check(bias.is_cuda and bias.device == A.device and bias.dtype == A.dtype and bias.is_contiguous() and
-               bias.numel() == size_n, "bias must be a contiguous [size_n] tensor of A's dtype on A's device")
-        epi = _lib.Epilogue(bias.data_ptr(), 0, 0)
+        # fused epilogue (include/petit_amd.h, petit_epilogue): c = round16(act(acc * gs + bias[n]))
+        if bias is not None:
+            _check(bias.is_cuda and bias.device == A.device and bias.dtype == A.dtype and bias.is_contiguous() and
+                   bias.numel() == size_n, "bias must be a contiguous [size_n] tensor of A's dtype on A's device")
+        epi = _lib.Epilogue(bias.data_ptr() if bias is not None else None, act, 0)
         fn = _lib.lib.petit_gemm_fp4_fp16_grid_ex if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid_ex
         with torch.cuda.device(A.device):
             err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
@@ -181,22 +189,22 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
     return c
 
 
-def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None) -> torch.Tensor:
-    """fp4.cc:163-209 (MulNvFp4A16); `bias` (optional, not in the reference) is fused into the epilogue."""
+def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
+    """fp4.cc:163-209 (MulNvFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue."""
     if s.dim() != 2 or s.size(1) == 0 or size_k // s.size(1) != 16:
         raise RuntimeError(f"Only groupsize = 16 is supported. size_k = {size_k}, s.size(1) = {s.size(-1)}")
     _check(s.numel() == size_n * size_k // 16, "s does not hold size_n * size_k / 16 scales")
-    return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias)
+    return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None) -> torch.Tensor:
-    """fp4.cc:211-260 (MulMxFp4A16); `bias` (optional, not in the reference) is fused into the epilogue."""
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
+    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue."""
     _check(B.size(0) == size_n // _LAYOUT_N, f"B.size(0) = {B.size(0)} is not size_n / 16 = {size_n // _LAYOUT_N}")
     _check(B.size(1) == size_k * _LAYOUT_N // _PACK,
            f"B.size(1) = {B.size(1)} is not packed size = {size_k * _LAYOUT_N // _PACK}")
     _check(s.size(0) == size_n // 32, f"s.size(0) = {s.size(0)} is not size_n / 32 = {size_n // 32}")
     _check(s.size(1) == size_k, f"s.size(1) = {s.size(1)} is not size_k = {size_k}")
-    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias)
+    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def get_fp4_solutions(*args) -> list:

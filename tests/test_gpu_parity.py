@@ -392,6 +392,50 @@ def test_fused_bias_epilogue(pk, kind, is_bf16, m, n, k, splitk):
             pk.ops.set_workspace(None)
 
 
+@pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (7, 96, 1024), (16, 64, 1024), (40, 128, 3072), (130, 256, 1024), (300, 544, 512)])
+@pytest.mark.parametrize("kind,is_bf16,with_bias", [("nv", True, False), ("nv", True, True), ("nv", False, True), ("mx", True, False), ("mx", False, True)])
+def test_fused_silu_mul_epilogue(pk, kind, is_bf16, with_bias, m, n, k):
+    """activation="silu_mul": c[m, j] = silu(y[m, j]) * y[m, j + n/2] with y = acc * gs (+ bias), one rounding.  Every
+    enumerated kernel that can serve it (even n-tiles per wave), the default pick, and the refusal of the others."""
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    a, q, s, gs = random_problem(kind, m, n, k, 555 + m + n + k, is_bf16, mx_band=(122, 130))
+    y = oracle_ref(kind, a, is_bf16, q, s, gs).astype(np.float64) * 0.05          # keep silu in its curved range
+    gs *= 0.05
+    bias = (torch.randn(n, generator=torch.Generator().manual_seed(n)) * 0.5).to(dtype) if with_bias else None
+    if bias is not None:
+        y = y + bias.float().numpy().astype(np.float64)[None, :]
+    gate, up = y[:, : n // 2], y[:, n // 2:]
+    ref = gate / (1.0 + np.exp(-gate)) * up
+    ad, qd = from_bits(a, dtype).to(DEV), torch.from_numpy(q).to(DEV)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+    if kind == "nv":
+        b, sp = pk.repack_nvfp4(qd.view(torch.int32), n, k), pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+        mul = pk.mul_nvfp4_a16
+    else:
+        b, sp = pk.repack_mxfp4(qd.view(torch.int32), n, k), pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+        mul = pk.mul_mxfp4_a16
+    bd = bias.to(DEV) if bias is not None else None
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = dtype
+    h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+    served = refused = 0
+    for sid in [-1] + list(pk.ops.get_fp4_solutions(h, m, n, k)):
+        nt = (sid >> 52) & 0xF if sid >= 0 else 2
+        if nt % 2:
+            with pytest.raises(RuntimeError, match="No kernel implementation"):
+                mul(ad, b, sp, gsd, m, n, k, sid, bias=bd, activation="silu_mul")
+            refused += 1
+            continue
+        c = mul(ad, b, sp, gsd, m, n, k, sid, bias=bd, activation="silu_mul")
+        assert c.shape == (m, n // 2) and c.dtype == dtype
+        cf = to_f32(bits(c), is_bf16).astype(np.float64)
+        # two rounded-once f32 factors multiplied: twice the relative bound of the plain GEMM, same absolute floor
+        err = np.abs(cf - ref)
+        assert (err <= np.maximum(1e-2, 2e-2 * np.abs(ref))).all(), f"sid {sid:#x}: max err {err.max()}"
+        served += 1
+    assert served >= 2
+
+
 # --- BASELINE.json full sizes: oracle on the whole problem + size-independent properties --
 
 @pytest.mark.parametrize("m", [1, 16])
@@ -496,6 +540,18 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
             #     of sum|a||w| (and typically ~3 % of the output's rms)
             assert (np.abs(c - full)[fin] <= 2e-2 * sum_abs[fin] + 1e-2).all()
             assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 6e-2 * np.sqrt(np.mean(full[fin] ** 2))
+        # the fused SiLU-mul epilogue on the native kernels (even n-tiles per wave), against the exact-semantics oracle
+        if n % 32 == 0 and fin.all() and np.abs(exact).max() < 50:
+            gate, up = exact.astype(np.float64)[:, : n // 2], exact.astype(np.float64)[:, n // 2:]
+            ref_act = gate / (1.0 + np.exp(-gate)) * up
+            qd = torch.from_numpy(q).to(DEV)
+            b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
+            sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+            gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+            for sid in [x for x in native if ((x >> 52) & 0xF) % 2 == 0][:3]:
+                c = pk.mul_mxfp4_a16(from_bits(a_bits, dtype).to(DEV), b, sp, gsd, m, n, k, sid, activation="silu_mul")
+                cf = to_f32(bits(c), is_bf16).astype(np.float64)
+                assert (np.abs(cf - ref_act) <= np.maximum(2e-2, 2e-2 * np.abs(ref_act))).all()
     finally:
         pk.ops.set_workspace(None)
         pk.ops.enable_native_fp4(False)

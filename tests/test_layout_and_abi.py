@@ -222,9 +222,13 @@ def test_epilogue_struct_is_validated_without_a_gpu():
     from petit_kernel import _lib
     hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
     for fn in (_lib.lib.petit_gemm_fp4_fp16_grid_ex, _lib.lib.petit_gemm_mxfp4_fp16_grid_ex):
-        epi = _lib.Epilogue(None, 1, 0)                       # an activation nobody implements yet
+        epi = _lib.Epilogue(None, 7, 0)                       # an activation nobody implements
         assert fn(None, None, None, None, None, 1, 64, 256, C.byref(hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO),
                   C.byref(epi), None) == _lib.PETIT_ERROR_BAD_ARGUMENT
+        epi = _lib.Epilogue(None, 1, 0)                       # SiLU-mul needs gate / up halves of whole n-tiles
+        fake = C.c_void_p(256)                                # never dereferenced: the shape check comes first
+        assert fn(fake, fake, fake, fake, fake, 1, 48, 256, C.byref(hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO),
+                  C.byref(epi), None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
         epi = _lib.Epilogue(None, 0, 0)                       # empty problem: ok, nothing enqueued
         assert fn(None, None, None, None, None, 0, 64, 256, C.byref(hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO),
                   C.byref(epi), None) == 0
