@@ -334,6 +334,89 @@ def test_cxx_api_end_to_end(pk, tmp_path, kind, is_bf16, m, n, k):
     check_gemm(c_bits, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
+def test_hip_graph_capture_and_replay(pk):
+    """No entry point synchronises the host or allocates behind the caller's back (SURVEY.md section 8b "Threading /
+    streams"): repack + GEMM (plain, fused, native two-launch path) are captured into one HIP graph, the inputs are
+    then changed in place, and a replay must produce the new problem's result."""
+    m, n, k = 4, 128, 1024
+    a1, q1, s1, gs1 = random_problem("mx", m, n, k, 1, True)
+    a2, q2, s2, gs2 = random_problem("mx", m, n, k, 2, True)
+    a = from_bits(a1, torch.bfloat16).to(DEV)
+    q = torch.from_numpy(q1).to(DEV)
+    sc = torch.from_numpy(s1).to(DEV)
+    gsd = torch.tensor([gs1], dtype=torch.float32, device=DEV)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16
+    h.b_type = pk.DataType.mxfloat4_e2m1
+    pk.ops.enable_native_fp4(True)
+    ws = torch.empty(pk.ops.native_workspace_bytes(m, k), dtype=torch.uint8, device=DEV)
+    pk.ops.set_workspace(ws)
+    try:
+        native = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 32) & 7 == 2][0]
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            def run():
+                b = pk.repack_mxfp4(q.view(torch.int32), n, k)
+                sp = pk.process_mxfp4_scales(sc, n, k)
+                return (pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, -1),
+                        pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, -1, activation="silu_mul"),
+                        pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, native))
+            run()                                   # warm-up outside capture (module load)
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                outs = run()
+            a.copy_(from_bits(a2, torch.bfloat16))
+            q.copy_(torch.from_numpy(q2))
+            sc.copy_(torch.from_numpy(s2))
+            gsd.fill_(gs2)
+            g.replay()
+            stream.synchronize()
+        ref = oracle_ref("mx", a2, True, q2, s2, gs2)
+        sum_abs = oracle_sum_abs("mx", a2, True, q2, s2, gs2)
+        check_gemm(bits(outs[0]), ref, True, sum_abs)
+        y = ref.astype(np.float64)
+        with np.errstate(over="ignore"):
+            act = y[:, : n // 2] / (1.0 + np.exp(-y[:, : n // 2])) * y[:, n // 2:]
+        cf = to_f32(bits(outs[1]), True).astype(np.float64)
+        fin = np.isfinite(act) & (np.abs(act) < 1e30)
+        assert (np.abs(cf - act)[fin] <= np.maximum(1e-2, 2e-2 * np.abs(act))[fin]).all()
+        cn = to_f32(bits(outs[2]), True).astype(np.float64)
+        assert (np.abs(cn - ref) <= 2e-2 * sum_abs + 1e-2).all()
+    finally:
+        pk.ops.set_workspace(None)
+        pk.ops.enable_native_fp4(False)
+
+
+def test_concurrent_host_threads_and_streams(pk):
+    """Stateless after static init (gemm_fp4_fp16_grid.cc:15-18,31-33 in the reference): four host threads, each on its
+    own stream with its own problem, hammer the library concurrently; every result must be its own problem's."""
+    import threading
+    probs = []
+    for i, (m, n, k, kind, is_bf16) in enumerate([(1, 256, 2048, "nv", True), (9, 96, 1024, "mx", True),
+                                                   (40, 64, 3072, "nv", False), (130, 128, 1024, "nv", True)]):
+        a, q, s, gs = random_problem(kind, m, n, k, 900 + i, is_bf16)
+        probs.append((m, n, k, kind, is_bf16, a, q, s, gs, oracle_ref(kind, a, is_bf16, q, s, gs),
+                      oracle_sum_abs(kind, a, is_bf16, q, s, gs)))
+    errors = []
+
+    def worker(p):
+        try:
+            m, n, k, kind, is_bf16, a, q, s, gs, ref, sum_abs = p
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(20):
+                    check_gemm(run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k), ref, is_bf16, sum_abs)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(p,)) for p in probs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_offline_repack_matches_device(pk):
     """petit_kernel.offline (CPU, checkpoint-side tooling) == the device repack, bit for bit, and the GEMM
     accepts the CPU-packed tensors."""
