@@ -351,7 +351,7 @@ struct StreamCfg {
     static_assert(kThreads <= 1024, "workgroup too large");
     static_assert(AM == 0 || (MT == 1 && (AM == 1 || AM == 2 || AM == 4 || AM == 8 || AM == 16)),
                   "staged path: MT == 1, AM in {1,2,4,8,16}");
-    static_assert(AM <= 4 || (!AT::kSplit && !AT::kBfp), "AM = 8 / 16: plain bf16 / fp16 activations only");
+    static_assert(AM <= 4 || !AT::kBfp, "AM = 8 / 16: not with block-floating-point activations");
     static_assert(AM == 0 || KS % SL == 0, "stage length must divide the span");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(!AT::kBfp || (AM > 0 && KS >= 4 && FMT == 0), "block-floating-point A: staged NVFP4 path only");
