@@ -11,3 +11,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_write_${TAG}.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_sq_${TAG}.log 2>&1
 cd $R; cat gpurun_out/bench_${TAG}.json; head -3 gpurun_out/prof_${TAG}/bench_kernel_stats.csv | cut -c1-300
+# MFMA utilisation at M = 512 (BASELINE config 5): the default (tiled dequant) kernel and the native-FP4 kernel on gate_up
+cd /tmp
+for v in "nv tiled" "mx native"; do
+  set -- $v
+  EXTRA=""; [ "$2" = "native" ] && EXTRA="--native"
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$2_${TAG} -o p -- python3 $R/tools/profile_one.py --m 512 --n 57344 --k 8192 --fmt $1 $EXTRA --iters 20 > $R/gpurun_out/pmc_mfma_$2_${TAG}.log 2>&1
+done
+cd $R

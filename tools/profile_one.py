@@ -22,6 +22,7 @@ ap.add_argument("--m", type=int, default=1)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--solution", default="auto")
 ap.add_argument("--fmt", default="nv")
+ap.add_argument("--native", action="store_true", help="mx only: run the fastest-looking native-FP4 kernel (largest tile)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 n, k, m = a.n, a.k, a.m
@@ -42,6 +43,18 @@ gs = torch.ones(1, device=dev)
 hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1 if a.fmt == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1,
                            _lib.CXX_DTYPE_BF16, 0)
 sid = _lib.PETIT_SOLUTION_AUTO if a.solution == "auto" else int(a.solution, 16)
+if a.native:
+    _lib.lib.petit_enable_native_fp4(1)
+    ws = torch.empty(int(_lib.lib.petit_native_workspace_bytes(m, k)), dtype=torch.uint8, device=dev)
+    _lib.lib.petit_set_workspace(C.c_void_p(ws.data_ptr()), C.c_uint64(ws.numel()))
+    cnt = C.c_uint(0)
+    _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, None, C.byref(cnt))
+    ids = (C.c_uint64 * cnt.value)()
+    _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, ids, C.byref(cnt))
+    native = [i for i in ids if (i >> 32) & 7 == 2]
+    if a.solution == "auto":   # tile_m * n-tiles per wave: the 128 x 256 shape
+        sid = max(native, key=lambda i: (i & 0xFF) * ((i >> 52) & 0xF))
+    print("native solution", hex(sid), _lib.describe_solution(sid))
 fn = _lib.lib.petit_gemm_fp4_fp16_grid if a.fmt == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
 torch.cuda.synchronize()
 for i in range(a.iters):
