@@ -326,7 +326,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
 //         tiles for AM = 8 / 16 (8 KiB per wave either way).  Measured on MI355X at
 //         M = 1, 8192^2: the 36 four-lane buffer_loads per span of the direct path cost
 //         3 us of a 12 us launch (TA issue-bound), see DESIGN.md.
-//   ABL   ablation bits for tools/ablate (0 in every shipped kernel):
+//   ABL   ablation bits for tools/ablate (0 in every shipped kernel; 16 = per-wave s_memrealtime stamps into p.workspace):
 //         1 no activation loads, 2 no unpack, 4 no MFMA, 8 empty kernel
 //   PA    direct path (AM == 0) only: how many tiles ahead the activation fragments are
 //         requested from L2 (ring of PA fragment sets; PA divides KS)
@@ -375,6 +375,9 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned wn = wave % WN, wk = wave / WN;
     const unsigned r = lane & 15u, g = lane >> 4;
+    [[maybe_unused]] unsigned long long ts[4] = {0, 0, 0, 0};
+    if constexpr (ABL & 16)
+        ts[0] = __builtin_amdgcn_s_memrealtime();
 
     const unsigned ktiles = p.k / kTileK;
     const unsigned nspans = ktiles / KS;
@@ -663,6 +666,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                         }
                     }
                 }
+                if constexpr (ABL & 16) { // tile consumed (its MFMAs issued): first and last tile of the wave
+                    if (T == 0 && sp == sp_begin)
+                        ts[1] = __builtin_amdgcn_s_memrealtime();
+                    if constexpr (kLast && T == KS - 1)
+                        ts[2] = __builtin_amdgcn_s_memrealtime();
+                }
                 if constexpr (kRefill) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
@@ -812,6 +821,14 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             } else {
                 emit(v, tile / (MT * NT), (tile / NT) % MT, tile % NT, item & 63u);
             }
+        }
+    }
+    if constexpr (ABL & 16) {
+        ts[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.workspace) +
+                                      ((size_t)blockIdx.x * (WN * WK) + wave) * 4;
+            dst[0] = ts[0], dst[1] = ts[1], dst[2] = ts[2], dst[3] = ts[3];
         }
     }
 }

@@ -14,8 +14,9 @@ template <class AT, int MT, int NT, int WN, int WK, int D, int AM, int ABL> stat
 
 // variant: (AT,MT,NT,WN,WK,D,AM) 0 = bfp (1,1,1,8,8,1) [bench default]  1 = bf16 (1,1,1,8,8,1)  2 = bf16 (1,2,1,4,4,16)  3 = bf16 (1,2,1,8,4,0)
 extern "C" int ablate_launch(int variant, int abl, void *c, const void *a, const void *w, const void *s, const float *gs,
-                             unsigned m, unsigned n, unsigned k, void *stream) {
+                             unsigned m, unsigned n, unsigned k, void *stream, void *stamps) {
     GemmArgs g{};
+    g.workspace = (float *)stamps;
     g.c = c, g.a = a, g.w = w, g.s = s, g.gs = gs, g.m = m, g.n = n, g.k = k;
     hipStream_t st = (hipStream_t)stream;
 #define CASE(V, AT, MT, NT, WN, WK, D, AM)                                 \
@@ -29,6 +30,7 @@ extern "C" int ablate_launch(int variant, int abl, void *c, const void *a, const
         case 5: launch<AT, MT, NT, WN, WK, D, AM, 5>(g, st); return 0;        \
         case 7: launch<AT, MT, NT, WN, WK, D, AM, 7>(g, st); return 0;        \
         case 8: launch<AT, MT, NT, WN, WK, D, AM, 8>(g, st); return 0;        \
+        case 16: launch<AT, MT, NT, WN, WK, D, AM, 16>(g, st); return 0;      \
         default: return -1;                                           \
         }                                                             \
     }
