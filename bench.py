@@ -118,6 +118,11 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
+    if not (ROOT / "petit-kernel_amd" / "lib" / "libpetit_amd.so").exists() and rank == 0:
+        import __graft_entry__            # a checkout without built artefacts: build once (hipcc), never fall back
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
     import petit_kernel  # fails loudly when libpetit_amd.so is missing
 
     bytes_per_step = algorithmic_bytes(M, N, K, GROUP)
