@@ -27,289 +27,9 @@
 //    tile.
 #pragma once
 
-#include <hip/hip_runtime.h>
-
-#include <type_traits>
-
-#include "layout.h"
-#include "petit_internal.h"
+#include "device_common.cuh"
 
 namespace petit_amd {
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-
-enum : int { kFmtNv = 0, kFmtMx = 1 };
-
-// gfx940-family cache-policy bits of the buffer intrinsics' aux operand.
-enum : int { kAuxDefault = 0, kAuxNt = 2 };
-
-struct Bf16 {
-    using frag = bf16x8;
-    static constexpr int kType = kDataTypeBf16;
-    static constexpr bool kSplit = false, kBfp = false;
-};
-struct Fp16 {
-    using frag = f16x8;
-    static constexpr int kType = kDataTypeFp16;
-    static constexpr bool kSplit = false, kBfp = false;
-};
-// bf16 activations on the fp16 pipeline (staged path only).  The fp16 unpack of an
-// NVFP4 word is 8 VALU (convert + v_pk_mul_f16) against 12 for bf16 (convert to f32,
-// v_pk_mul_f32, v_perm_b32), and the unpack is what the small-M kernel is exposed on.
-// bf16 has 8 significant bits, fp16 has 11, so a bf16 value is exactly an fp16 value
-// whenever its exponent fits.  Each wave therefore rescales ITS span of every
-// activation row by a power of two (block floating point: 2^-sh with sh chosen from
-// the span's largest exponent so the maximum lands in [2^14, 2^15)), converts to
-// fp16, accumulates that span in f32 and multiplies the span's partial sum back by
-// 2^sh before it joins the running total.  Exact except for elements more than 2^29
-// below their span's maximum (fp16 subnormal range), whose contribution to the sum is
-// below 2^-29 of the largest term -- far under the single bf16 rounding of the result.
-struct Bf16Bfp {
-    using frag = f16x8;
-    static constexpr int kType = kDataTypeBf16;
-    static constexpr bool kSplit = false, kBfp = true;
-};
-// fp16 activations against MXFP4 weights (a capability the reference does not have:
-// fp4/warp_schedule_fp16.cuh:22-26 static_asserts it away).  e8m0 block scales span
-// 2^-127..2^127, far outside fp16, so the weights are dequantised to bf16 (exact) and
-// every fp16 activation a is split EXACTLY into two bf16 numbers a = hi + lo
-// (hi = the top 8 significant bits, lo = the remaining <= 3): two bf16 MFMAs per
-// fragment, f32 accumulation, no precision lost anywhere.
-struct Fp16Split {
-    using frag = bf16x8;
-    static constexpr int kType = kDataTypeFp16;
-    static constexpr bool kSplit = true, kBfp = false;
-};
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
-    // raw buffer, no swizzle, bounds-checked: 0x00020000 = DATA_FORMAT_32
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
-}
-
-__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff,
-                                            int aux) {
-    // aux must be a literal for the builtin
-    if (aux == kAuxNt)
-        return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxNt));
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxDefault));
-}
-
-// --- unpack: one 32-bit word = 8 consecutive-k E2M1 values -> one MFMA operand --
-
-template <int SEL> __device__ __forceinline__ f32x2 cvt_fp4_f32(unsigned w, float scale) {
-    return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, scale, SEL);
-}
-template <int SEL> __device__ __forceinline__ bf16x2 cvt_fp4_bf16(unsigned w, float scale) {
-    return __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, SEL);
-}
-template <int SEL> __device__ __forceinline__ f16x2 cvt_fp4_f16(unsigned w, float scale) {
-    return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, scale, SEL);
-}
-
-// NVFP4 -> bf16: exact (fp4 x e4m3 needs <= 5 significant bits), so the f32
-// products are turned into bf16 by TRUNCATION -- one v_perm_b32 per pair picking
-// the two high halves -- instead of v_cvt_pk_bf16_f32, which measures ~10 cycles
-// per wave-instruction on gfx950 against 4 for v_perm_b32 (tools/probes/valu_rate).
-// NOTE (hipcc / ROCm 7.2): __builtin_bit_cast applied directly to a vector ELEMENT
-// expression (p.y, h[d]) silently reads element 0.  Always copy the element into a
-// scalar first -- every bit_cast in this file takes a named scalar or a whole vector.
-__device__ __forceinline__ unsigned trunc_pack_bf16(f32x2 p) {
-    const float x = p.x, y = p.y;
-    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y), __builtin_bit_cast(unsigned, x), 0x07060302u);
-}
-__device__ __forceinline__ bf16x8 unpack_nv(Bf16, unsigned w, float s) {
-    const f32x2 p0 = cvt_fp4_f32<0>(w, 1.0f) * s;
-    const f32x2 p1 = cvt_fp4_f32<1>(w, 1.0f) * s;
-    const f32x2 p2 = cvt_fp4_f32<2>(w, 1.0f) * s;
-    const f32x2 p3 = cvt_fp4_f32<3>(w, 1.0f) * s;
-    return __builtin_bit_cast(bf16x8, u32x4{trunc_pack_bf16(p0), trunc_pack_bf16(p1), trunc_pack_bf16(p2), trunc_pack_bf16(p3)});
-}
-// NVFP4 -> fp16: exact (|fp4 * s| <= 2688, >= 2^-10).
-__device__ __forceinline__ f16x8 unpack_nv(Fp16, unsigned w, float s) {
-    const f16x2 s2 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(s, s));
-    f16x2 q0 = cvt_fp4_f16<0>(w, 1.0f) * s2;
-    f16x2 q1 = cvt_fp4_f16<1>(w, 1.0f) * s2;
-    f16x2 q2 = cvt_fp4_f16<2>(w, 1.0f) * s2;
-    f16x2 q3 = cvt_fp4_f16<3>(w, 1.0f) * s2;
-    return f16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
-}
-__device__ __forceinline__ f16x8 unpack_nv(Fp16, unsigned w, float s);
-__device__ __forceinline__ f16x8 unpack_nv(Bf16Bfp, unsigned w, float s) { return unpack_nv(Fp16{}, w, s); }
-// MXFP4 -> bf16: the e8m0 block scale (a power of two) rides in the convert.
-__device__ __forceinline__ bf16x8 unpack_mx(Bf16, unsigned w, float s) {
-    bf16x2 q0 = cvt_fp4_bf16<0>(w, s);
-    bf16x2 q1 = cvt_fp4_bf16<1>(w, s);
-    bf16x2 q2 = cvt_fp4_bf16<2>(w, s);
-    bf16x2 q3 = cvt_fp4_bf16<3>(w, s);
-    return bf16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
-}
-
-__device__ __forceinline__ bf16x8 unpack_mx(Fp16Split, unsigned w, float s) { return unpack_mx(Bf16{}, w, s); }
-
-// 8 fp16 values -> (hi, lo) bf16 fragments with hi + lo == the fp16 value exactly.
-__device__ __forceinline__ void split_f16(const u32x4 &h, u32x4 &hi, u32x4 &lo) {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        const unsigned hd = h[d]; // scalar copy first: see the bit_cast note above
-        const f16x2 p = __builtin_bit_cast(f16x2, hd);
-        const float f0 = (float)p[0], f1 = (float)p[1];             // exact
-        const unsigned u0 = __builtin_bit_cast(unsigned, f0) & 0xffff0000u;
-        const unsigned u1 = __builtin_bit_cast(unsigned, f1) & 0xffff0000u;
-        const float l0 = f0 - __builtin_bit_cast(float, u0);       // <= 3 significant bits: exact,
-        const float l1 = f1 - __builtin_bit_cast(float, u1);       // and exactly a bf16
-        hi[d] = (u0 >> 16) | u1;
-        lo[d] = (__builtin_bit_cast(unsigned, l0) >> 16) | (__builtin_bit_cast(unsigned, l1) & 0xffff0000u);
-    }
-}
-
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// e4m3 byte SEL of a packed dword -> f32 (OCP e4m3 on gfx950).
-template <int SEL> __device__ __forceinline__ float e4m3_byte(unsigned packed) {
-    return __builtin_amdgcn_cvt_f32_fp8((int)packed, SEL);
-}
-// e8m0 byte SEL of a packed dword -> f32 2^(e-127)  (dequant.cuh:198-203).
-template <int SEL> __device__ __forceinline__ float e8m0_byte(unsigned packed) {
-    return __builtin_bit_cast(float, ((packed >> (8 * SEL)) & 0xffu) << 23);
-}
-
-__device__ __forceinline__ unsigned pack2(Bf16, float lo, float hi) {
-    bf16x2 q = __builtin_convertvector(f32x2{lo, hi}, bf16x2); // RNE, qgemm.cuh:161-176
-    return __builtin_bit_cast(unsigned, q);
-}
-__device__ __forceinline__ unsigned pack2(Bf16Bfp, float lo, float hi) { return pack2(Bf16{}, lo, hi); }
-__device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi);
-__device__ __forceinline__ unsigned pack2(Fp16Split, float lo, float hi) { return pack2(Fp16{}, lo, hi); }
-__device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi) {
-    f16x2 q = __builtin_convertvector(f32x2{lo, hi}, f16x2); // RNE
-    return __builtin_bit_cast(unsigned, q);
-}
-
-// The epilogue of every kernel: 4 consecutive n of one output row, x global scale (+ bias[n..n+3]
-// when the caller fused one, petit_epilogue in include/petit_amd.h), ONE round-to-nearest-even to
-// the 16-bit output type (qgemm.cuh:95-192 in the reference, which has no bias).
-template <class AT> __device__ __forceinline__ uint2 finish4(const f32x4 v, const float gs, const void *bias, const unsigned n) {
-    float b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-        const uint2 raw = *reinterpret_cast<const uint2 *>((const char *)bias + (size_t)n * 2);
-        const unsigned w0 = raw.x, w1 = raw.y; // named scalars: see the bit_cast note in DESIGN.md section 9
-        if constexpr (AT::kType == kDataTypeBf16) {
-            const unsigned b0 = w0 << 16, b1 = w0 & 0xffff0000u, b2 = w1 << 16, b3 = w1 & 0xffff0000u;
-            b[0] = __builtin_bit_cast(float, b0), b[1] = __builtin_bit_cast(float, b1);
-            b[2] = __builtin_bit_cast(float, b2), b[3] = __builtin_bit_cast(float, b3);
-        } else {
-            const f16x2 h0 = __builtin_bit_cast(f16x2, w0), h1 = __builtin_bit_cast(f16x2, w1);
-            const _Float16 e0 = h0[0], e1 = h0[1], e2 = h1[0], e3 = h1[1];
-            b[0] = (float)e0, b[1] = (float)e1, b[2] = (float)e2, b[3] = (float)e3;
-        }
-    }
-    uint2 o;
-    o.x = pack2(AT{}, __builtin_fmaf(v[0], gs, b[0]), __builtin_fmaf(v[1], gs, b[1]));
-    o.y = pack2(AT{}, __builtin_fmaf(v[2], gs, b[2]), __builtin_fmaf(v[3], gs, b[3]));
-    return o;
-}
-
-// SiLU-mul epilogue (petit_epilogue.activation = 1): `gate` holds 4 consecutive columns j of the first half of
-// the GEMM's N, `up` the same columns of the second half; out[j] = silu(y_gate[j]) * y_up[j], y = acc*gs + bias,
-// rounded once.  bias (if any) spans the full N: gate part at n, up part at n + n_half.
-template <class AT>
-__device__ __forceinline__ uint2 finish4_silu_mul(const f32x4 gate, const f32x4 up, const float gs, const void *bias,
-                                                  const unsigned n, const unsigned n_half) {
-    float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
-    if (bias) {
-        auto load4 = [&](unsigned col, float *b) {
-            const uint2 raw = *reinterpret_cast<const uint2 *>((const char *)bias + (size_t)col * 2);
-            const unsigned w0 = raw.x, w1 = raw.y;
-            if constexpr (AT::kType == kDataTypeBf16) {
-                const unsigned b0 = w0 << 16, b1 = w0 & 0xffff0000u, b2 = w1 << 16, b3 = w1 & 0xffff0000u;
-                b[0] = __builtin_bit_cast(float, b0), b[1] = __builtin_bit_cast(float, b1);
-                b[2] = __builtin_bit_cast(float, b2), b[3] = __builtin_bit_cast(float, b3);
-            } else {
-                const f16x2 h0 = __builtin_bit_cast(f16x2, w0), h1 = __builtin_bit_cast(f16x2, w1);
-                const _Float16 e0 = h0[0], e1 = h0[1], e2 = h1[0], e3 = h1[1];
-                b[0] = (float)e0, b[1] = (float)e1, b[2] = (float)e2, b[3] = (float)e3;
-            }
-        };
-        load4(n, bg);
-        load4(n + n_half, bu);
-    }
-    float o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float g = __builtin_fmaf(gate[i], gs, bg[i]), u = __builtin_fmaf(up[i], gs, bu[i]);
-        o[i] = g / (1.0f + __expf(-g)) * u;
-    }
-    uint2 r;
-    r.x = pack2(AT{}, o[0], o[1]);
-    r.y = pack2(AT{}, o[2], o[3]);
-    return r;
-}
-
-// Logical n-tile L of a kernel's grid -> physical n-tile of W.  Plain GEMM: identity.  SiLU-mul: consecutive
-// logical tiles (2p, 2p+1) are the gate tile p and the up tile p + ntiles/2, so that one wave (even NT) holds both.
-__device__ __forceinline__ unsigned physical_tile(unsigned l, unsigned ntiles, unsigned act) {
-    return act ? (l >> 1) + (l & 1u) * (ntiles >> 1) : l;
-}
-
-// Scale record of one span for one n-tile: KS*2 bytes (NV) / KS bytes (MX).
-template <int FMT, int KS> struct ScaleRec {
-    static constexpr int kBytes = (FMT == kFmtNv ? 2 : 1) * KS;
-    static constexpr int kDwords = (kBytes + 3) / 4;
-    unsigned d[kDwords];
-};
-
-template <int FMT, int KS>
-__device__ __forceinline__ ScaleRec<FMT, KS> load_scale_rec(__amdgpu_buffer_rsrc_t r, unsigned voff,
-                                                            unsigned soff) {
-    ScaleRec<FMT, KS> out;
-    constexpr int B = ScaleRec<FMT, KS>::kBytes;
-    if constexpr (B == 16) {
-        u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, kAuxNt));
-        out.d[0] = v[0], out.d[1] = v[1], out.d[2] = v[2], out.d[3] = v[3];
-    } else if constexpr (B == 8) {
-        u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxNt));
-        out.d[0] = v[0], out.d[1] = v[1];
-    } else if constexpr (B == 4) {
-        out.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxNt);
-    } else {
-        static_assert(B == 2, "span record is 2, 4, 8 or 16 bytes");
-        out.d[0] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, kAuxNt);
-    }
-    return out;
-}
-
-// The two group scales (NV) or the block scale (MX) of tile T of the span.
-template <int FMT, int KS, int T>
-__device__ __forceinline__ void tile_scales(const ScaleRec<FMT, KS> &rec, float &s_lo, float &s_hi) {
-    if constexpr (FMT == kFmtNv) {
-        constexpr int byte = 2 * T;
-        s_lo = e4m3_byte<byte % 4>(rec.d[byte / 4]);
-        s_hi = e4m3_byte<(byte + 1) % 4>(rec.d[(byte + 1) / 4]);
-    } else {
-        s_lo = s_hi = e8m0_byte<T % 4>(rec.d[T / 4]);
-    }
-}
-
-// Compile-time loop with a constant index (scale-record bytes, ring slots and
-// convert byte-selects must all be literals).
-template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // Compile-time configuration of one kernel instance.
 //   AT    Bf16 / Fp16 activations (and output)
