@@ -3,6 +3,6 @@
 #define PETIT_TU_AT Fp16Split
 #define PETIT_TU_FMT kFmtMx
 #define PETIT_TU_TABLE solutions_mx_f16
-#define PETIT_TU_NO_TILED 1
+#define PETIT_TU_SPLIT 1
 #define PETIT_TU_NATIVE_AT Fp16
 #include "stream_tu.inc"

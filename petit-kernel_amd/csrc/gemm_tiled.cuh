@@ -33,12 +33,14 @@ template <class AT_, int FMT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> s
     static constexpr int kThreads = 64 * WAVES;
     static constexpr int BM = 16 * MT;
     static constexpr int kRowU4 = 17;                     // 16 units of 16 B + 1 pad (bank spread)
-    static constexpr int kBufU4 = BM * kRowU4;            // one A tile image
+    static constexpr int kImgU4 = BM * kRowU4;            // one A tile image
+    // fp16 x MXFP4: the staging threads split each fp16 activation ONCE into two bf16 (hi + lo, exact), and the
+    // tile lives in LDS as two images; every weight fragment then meets both (two MFMAs instead of one)
+    static constexpr int kBufU4 = kImgU4 * (AT::kSplit ? 2 : 1);
     static constexpr int kUnitsPerThread = BM * 16 / kThreads;
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert((BM * 16) % kThreads == 0, "A tile must split evenly over the workgroup");
     static_assert(2 * kBufU4 * 16 <= 160 * 1024, "LDS budget");
-    static_assert(!AT::kSplit, "fp16 x MXFP4 is served by the streaming kernel only");
 };
 
 template <class Cfg>
@@ -118,9 +120,20 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
             wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], i * kTileBytes, kAuxDefault);
+    auto store_a_tile = [&](u32x4 *dst) {
 #pragma unroll
-    for (int i = 0; i < UPT; ++i)
-        smem[a_l_idx[i]] = astage[i];
+        for (int i = 0; i < UPT; ++i) {
+            if constexpr (AT::kSplit) {
+                u32x4 hi, lo;
+                split_f16(astage[i], hi, lo);
+                dst[a_l_idx[i]] = hi;
+                dst[a_l_idx[i] + Cfg::kImgU4] = lo;
+            } else {
+                dst[a_l_idx[i]] = astage[i];
+            }
+        }
+    };
+    store_a_tile(smem);
     __syncthreads();
 
     auto span_body = [&](const unsigned sp, auto last_c) {
@@ -168,20 +181,24 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
             // every m-tile: 4 fragments from LDS, 4*NTW MFMAs
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                u32x4 af[4];
+                u32x4 af[4], af_lo[AT::kSplit ? 4 : 1];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j) {
                     af[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j];
+                    if constexpr (AT::kSplit)
+                        af_lo[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j + Cfg::kImgU4];
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) // j outer: consecutive MFMAs hit different accumulators
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt)
+                    for (int nt = 0; nt < NTW; ++nt) {
                         acc[mt][nt] = mfma16(wf[nt][j], __builtin_bit_cast(Frag, af[j]), acc[mt][nt]);
+                        if constexpr (AT::kSplit)
+                            acc[mt][nt] = mfma16(wf[nt][j], __builtin_bit_cast(Frag, af_lo[j]), acc[mt][nt]);
+                    }
             }
             if constexpr (kNextA) {
-#pragma unroll
-                for (int i = 0; i < UPT; ++i)
-                    a_nxt[a_l_idx[i]] = astage[i];
+                store_a_tile(a_nxt);
                 __syncthreads();
             }
         });

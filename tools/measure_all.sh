@@ -15,6 +15,7 @@ python tools/tune.py --shapes $SH --ms 1,4,8,16 --fmt nv --dtype bf16 --only-def
 # M = 512 (BASELINE config 5): dequant kernels and the vendor 16-bit GEMM on the same shapes
 python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512 --fmt nv --dtype bf16 --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_nv_bf16.json > gpurun_out/${TAG}_tune_bigm_nv_bf16.log 2>&1
 python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512 --fmt nv --dtype f16 --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_nv_f16.json > gpurun_out/${TAG}_tune_bigm_nv_f16.log 2>&1
+python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 128,256,512 --fmt mx --dtype f16 --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_mx_f16.json > gpurun_out/${TAG}_tune_bigm_mx_f16.log 2>&1
 python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512 --fmt mx --dtype bf16 --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_bigm_mx_bf16.json > gpurun_out/${TAG}_tune_bigm_mx_bf16.log 2>&1
 # the opt-in native-FP4 kernels (MXFP4 weights x MXFP8-quantised activations) next to them
 python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 512,2048 --fmt mx --dtype bf16 --native --compare-dense --rotate-mb 640 --out gpurun_out/${TAG}_tune_native_mx_bf16.json > gpurun_out/${TAG}_tune_native_mx_bf16.log 2>&1
