@@ -178,6 +178,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
                 for (int nt = 0; nt < NTW; ++nt)
                     wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxDefault);
             }
+            // the step's global loads (next A tile, W refill) are requested before its MFMAs: hipcc otherwise
+            // sinks the A loads next to their LDS stores at the end of the step and every step exposes the
+            // whole L2 / HBM latency.  Only for the small tiles: with >= 64 accumulator registers the pinned
+            // loads cost the second wave per SIMD, which hides that latency better (measured both ways:
+            // 64x128 tiles +7 % at M = 256, 128x128 tiles -12 % at M = 512 / 2048).
+            if constexpr (MT * NTW <= 8)
+                __builtin_amdgcn_sched_barrier(0);
             // every m-tile: 4 fragments from LDS, 4*NTW MFMAs
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
