@@ -32,19 +32,27 @@ template <class AT_, int FMT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> s
     static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NTW = NTW_, WAVES = WAVES_, D = D_;
     static constexpr int kThreads = 64 * WAVES;
     static constexpr int BM = 16 * MT;
-    static constexpr int kRowU4 = 17;                     // 16 units of 16 B + 1 pad (bank spread)
+    // A tile in LDS.  Plain 16-bit activations go global -> LDS directly (buffer_load ... lds: no VGPR staging, no
+    // ds_write; probed in tools/probes/lds_dma_probe.hip: lane i of a wave-load lands at base + 16 i, out-of-range
+    // lanes write zeros).  That forces lane-linear placement, so rows are 16 units with an XOR swizzle instead of
+    // a pad: unit u of row r sits at position u ^ (r % 16), and the 16 rows a fragment read touches hit 16
+    // different bank groups.  The fp16 x MXFP4 split needs VALU on the way in and keeps the padded layout.
+    static constexpr bool kDma = !AT::kSplit;
+    static constexpr int kRowU4 = kDma ? 16 : 17;         // 16 units of 16 B (+ 1 pad: bank spread)
     static constexpr int kImgU4 = BM * kRowU4;            // one A tile image
     // fp16 x MXFP4: the staging threads split each fp16 activation ONCE into two bf16 (hi + lo, exact), and the
     // tile lives in LDS as two images; every weight fragment then meets both (two MFMAs instead of one)
     static constexpr int kBufU4 = kImgU4 * (AT::kSplit ? 2 : 1);
     static constexpr int kUnitsPerThread = BM * 16 / kThreads;
+    // 64 accumulator registers + direct-to-LDS staging fit two waves per SIMD; hipcc lands on 260 VGPRs unless told
+    static constexpr int kMinWavesPerSimd = (kDma && MT == 8 && NTW == 2) ? 2 : 1;
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert((BM * 16) % kThreads == 0, "A tile must split evenly over the workgroup");
     static_assert(2 * kBufU4 * 16 <= 160 * 1024, "LDS budget");
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_tiled_kernel(const GemmArgs p) {
     using AT = typename Cfg::AT;
     using Frag = typename AT::frag;
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
@@ -104,12 +112,37 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
         a_l_idx[i] = row * Cfg::kRowU4 + col;
     }
     const unsigned a_frag_base = r * Cfg::kRowU4 + g * 4; // + mt*16*kRowU4 + j
+    // direct-to-LDS staging: wave-load i of this wave covers rows 4*(i*WAVES + wave) .. +3; lane l -> row + l/16,
+    // position l%16, which receives unit (l%16) ^ (row%16) of that row
+    constexpr int kDmaLoads = Cfg::BM * 16 / 64 / WAVES; // wave-loads per wave per tile
+    // one VGPR: wave-load i differs from wave-load 0 only by 4*WAVES whole rows, a multiple of 16, so the swizzle
+    // term is the same and the row step rides in the SGPR offset
+    static_assert(!Cfg::kDma || (4 * WAVES) % 16 == 0, "direct-to-LDS staging: wave-loads must step by whole 16-row groups");
+    const unsigned dma_row0 = wave * 4 + (lane >> 4);
+    const unsigned dma_voff = dma_row0 * p.k * 2 + (((lane & 15u) ^ (dma_row0 & 15u)) * 16); // rows >= M: out of range -> zeros
+    auto dma_a_tile = [&](u32x4 *dst, unsigned kt) {
+        if constexpr (Cfg::kDma) {
+#pragma unroll
+            for (int i = 0; i < kDmaLoads; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__) // (the host pass knows neither the builtin nor the LDS address space)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void *)(dst + (i * WAVES + wave) * 64),
+                                                         16, dma_voff, i * (4 * WAVES) * p.k * 2 + kt * 256, 0, 0);
+#else
+                (void)dst, (void)kt;
+#endif
+            }
+        }
+    };
 
     // --- prologue
-    u32x4 astage[UPT];
+    u32x4 astage[Cfg::kDma ? 1 : UPT];
+    if constexpr (Cfg::kDma) {
+        dma_a_tile(smem, 0u);
+    } else {
 #pragma unroll
-    for (int i = 0; i < UPT; ++i)
-        astage[i] = buf_load16(a_rsrc, a_g_voff[i], 0u, kAuxDefault);
+        for (int i = 0; i < UPT; ++i)
+            astage[i] = buf_load16(a_rsrc, a_g_voff[i], 0u, kAuxDefault);
+    }
     ScaleRec<FMT, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -121,8 +154,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
         for (int nt = 0; nt < NTW; ++nt)
             wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], i * kTileBytes, kAuxDefault);
     auto store_a_tile = [&](u32x4 *dst) {
+        if constexpr (Cfg::kDma)
+            return; // already on its way into LDS
 #pragma unroll
-        for (int i = 0; i < UPT; ++i) {
+        for (int i = 0; i < (Cfg::kDma ? 0 : UPT); ++i) {
             if constexpr (AT::kSplit) {
                 u32x4 hi, lo;
                 split_f16(astage[i], hi, lo);
@@ -154,9 +189,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
             u32x4 *const a_nxt = smem + ((kt & 1u) ? 0 : Cfg::kBufU4);
             // next step's A tile: global -> registers now, LDS after this step's reads
             if constexpr (kNextA) {
+                if constexpr (Cfg::kDma) {
+                    dma_a_tile(a_nxt, kt + 1); // everybody left a_nxt at the barrier that ended the previous step
+                } else {
 #pragma unroll
-                for (int i = 0; i < UPT; ++i)
-                    astage[i] = buf_load16(a_rsrc, a_g_voff[i], (kt + 1) * 256, kAuxDefault);
+                    for (int i = 0; i < UPT; ++i)
+                        astage[i] = buf_load16(a_rsrc, a_g_voff[i], (kt + 1) * 256, kAuxDefault);
+                }
             }
             // unpack this step's weight words once
             Frag wf[NTW][4];
@@ -183,7 +222,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
             // whole L2 / HBM latency.  Only for the small tiles: with >= 64 accumulator registers the pinned
             // loads cost the second wave per SIMD, which hides that latency better (measured both ways:
             // 64x128 tiles +7 % at M = 256, 128x128 tiles -12 % at M = 512 / 2048).
-            if constexpr (MT * NTW <= 8)
+            if constexpr (MT * NTW <= 8 || Cfg::kDma)
                 __builtin_amdgcn_sched_barrier(0);
             // every m-tile: 4 fragments from LDS, 4*NTW MFMAs
 #pragma unroll
@@ -191,7 +230,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_tiled_kernel(const GemmArg
                 u32x4 af[4], af_lo[AT::kSplit ? 4 : 1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    af[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j];
+                    if constexpr (Cfg::kDma)
+                        af[j] = a_cur[(mt * 16 + r) * 16 + ((g * 4 + j) ^ r)];
+                    else
+                        af[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j];
                     if constexpr (AT::kSplit)
                         af_lo[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j + Cfg::kImgU4];
                 }
