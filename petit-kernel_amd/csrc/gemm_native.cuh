@@ -19,7 +19,8 @@
 //                 row / column, whichever lane holds the data bytes; opsel picks the byte of the VGPR.
 //
 // Two launches: quantize_act_kernel (A -> fp8 bytes in the operand's order + scales, into the
-// registered workspace) and gemm_native_kernel (tiled like gemm_tiled.cuh, A tile through LDS).
+// registered workspace) and gemm_native_kernel (tiled like gemm_tiled.cuh, A tile through LDS, written there by
+// direct global -> LDS loads).
 #pragma once
 
 #include "gemm_tiled.cuh"
@@ -95,17 +96,21 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const void *a, unsign
     }
 }
 
-//   MT, NTW, WAVES, D as in TiledCfg.  A tile image in LDS: BM rows x (128 data + 4 scale + 12 pad) B.
+//   MT, NTW, WAVES, D as in TiledCfg.  The A tile (BM rows x 128 fp8 bytes) and its scale bytes (BM x 4) go
+//   global -> LDS directly (buffer_load ... lds, see gemm_tiled.cuh): rows are 8 un-padded 16-byte units with an
+//   XOR swizzle (unit u of row r at position u ^ ((r / 2) % 8): the 16 rows of a fragment read spread over all
+//   banks and the two units a lane needs stay one aligned 32-byte pair), scales are one dword per row.
 template <class AT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct NativeCfg {
     using AT = AT_;
     static constexpr int KS = KS_, MT = MT_, NTW = NTW_, WAVES = WAVES_, D = D_;
     static constexpr int kThreads = 64 * WAVES;
     static constexpr int BM = 16 * MT;
-    static constexpr int kRowU4 = 9;                         // 8 data units + 1 unit holding the 4 scales
-    static constexpr int kBufU4 = BM * kRowU4;
-    static constexpr int kUnitsPerThread = BM * 8 / kThreads; // data units (16 B) per thread per tile
+    static constexpr int kDataU4 = BM * 8;                   // one tile image
+    static constexpr int kScaleU4 = kThreads / 4;            // one dword per thread (rows >= BM: junk zeros)
+    static constexpr int kDataLoads = BM * 8 / 64 / WAVES;   // 1 KiB wave-loads per wave per tile
     static_assert(KS % D == 0, "ring depth must divide the span");
-    static_assert((BM * 8) % kThreads == 0 && BM <= kThreads, "A tile must split evenly over the workgroup");
+    static_assert((BM * 8) % (64 * WAVES) == 0 && BM <= kThreads, "A tile must split evenly over the waves");
+    static_assert((8 * WAVES) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
 };
 
 template <class Cfg>
@@ -114,11 +119,9 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     constexpr int KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
     constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;
     constexpr unsigned kOob = 0x80000000u;
-    constexpr int UPT = Cfg::kUnitsPerThread;
 
-    // two tile images + one junk dword per thread: threads without a scale row store there, so the
-    // staging code is branch-free and every k-step stays one basic block (see the note at the MFMAs)
-    __shared__ u32x4 smem[2 * Cfg::kBufU4 + Cfg::kThreads / 4];
+    // [tile image 0][tile image 1][scale dwords 0][scale dwords 1]
+    __shared__ u32x4 smem[2 * Cfg::kDataU4 + 2 * Cfg::kScaleU4];
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -162,36 +165,31 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     // tools/probes): n-tiles beyond valid_nt and rows beyond M still read as zeros.  (The streaming
     // kernel keeps validity in the VGPR offset; here 12 VGPRs decide between one and two waves per SIMD.)
     const unsigned w_voff = lane * 16, s_voff = lane * kRecBytes;
-    // staging: data unit u = tid + i*kThreads -> row u/8 = tid/8 + i*kThreads/8, unit u%8 = tid%8
-    const unsigned a_g_voff = (tid >> 3) * p.k + (tid & 7u) * 16;
-    const unsigned a_l_idx = (tid >> 3) * Cfg::kRowU4 + (tid & 7u);
-    const unsigned a_unit_rows = Cfg::kThreads / 8; // rows between a thread's consecutive units
-    const bool has_scale_row = tid < (unsigned)Cfg::BM;
-    const unsigned qs_voff = has_scale_row ? tid * (p.k / 32) : kOob;
-    unsigned *const smem_u32 = reinterpret_cast<unsigned *>(smem);
-    // dword index of the row's scale unit in image 0 / image 1 (junk slot for threads without a row)
-    const unsigned qs_l_idx0 = has_scale_row ? (tid * Cfg::kRowU4 + 8) * 4 : 2 * Cfg::kBufU4 * 4 + tid;
-    const unsigned qs_l_idx1 = has_scale_row ? qs_l_idx0 + Cfg::kBufU4 * 4 : qs_l_idx0;
-    const unsigned a_frag_base = r * Cfg::kRowU4 + g * 2;  // + mt*16*kRowU4 (+1 for the second half)
-    const unsigned a_scale_byte = (r * Cfg::kRowU4 + 8) * 16 + g; // byte index of this lane's block scale
-
-    u32x4 astage[UPT];
-    unsigned sstage = 0;
-    auto load_stage = [&](unsigned kt) {
+    // direct-to-LDS staging.  Data: wave-load i of this wave covers rows 8*(i*WAVES + wave) .. +7, lane l -> row + l/8,
+    // position l%8, which receives unit (l%8) ^ ((row/2)%8).  Scales: wave w covers rows 64w .. 64w+63, one dword
+    // per lane (waves beyond BM read out of range and park zeros in the unused tail of the scale array).
+    const unsigned dma_row0 = wave * 8 + (lane >> 3);
+    const unsigned dma_voff = dma_row0 * p.k + (((lane & 7u) ^ ((dma_row0 >> 1) & 7u)) * 16);
+    const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * (p.k / 32) : kOob;
+    auto dma_stage = [&](unsigned kt, unsigned buf) {
+#if defined(__HIP_DEVICE_COMPILE__) // (the host pass knows neither the builtin nor the LDS address space)
+        u32x4 *const data = smem + buf * Cfg::kDataU4;
 #pragma unroll
-        for (int i = 0; i < UPT; ++i)
-            astage[i] = buf_load16(qa_rsrc, a_g_voff, i * a_unit_rows * p.k + kt * 128, kAuxDefault);
-        sstage = __builtin_amdgcn_raw_buffer_load_b32(qs_rsrc, qs_voff, kt * 4, 0);
+        for (int i = 0; i < Cfg::kDataLoads; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * WAVES + wave) * 64), 16,
+                                                     dma_voff, i * (8 * WAVES) * p.k + kt * 128, 0, 0);
+        u32x4 *const sc = smem + 2 * Cfg::kDataU4 + buf * Cfg::kScaleU4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, kt * 4, 0, 0);
+#else
+        (void)kt, (void)buf;
+#endif
     };
-    auto store_stage = [&](unsigned buf) {
-        u32x4 *const dst = smem + buf * Cfg::kBufU4;
-#pragma unroll
-        for (int i = 0; i < UPT; ++i)
-            dst[a_l_idx + i * a_unit_rows * Cfg::kRowU4] = astage[i];
-        smem_u32[buf ? qs_l_idx1 : qs_l_idx0] = sstage;
-    };
+    const unsigned swz = (r >> 1) & 7u;
+    const unsigned a_frag_lo = r * 8 + ((2 * g) ^ swz);      // + mt*16*8; the second half is the pair's other unit
+    const unsigned a_frag_hi = r * 8 + ((2 * g + 1) ^ swz);
+    const unsigned a_scale_byte = r * 4 + g;                 // + mt*16*4, byte index into the scale array
 
-    load_stage(0);
+    dma_stage(0, 0);
     ScaleRec<kFmtMx, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -202,7 +200,6 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
             wring[i][nt] = buf_load16(w_rsrc, w_voff, rel_tile(nt) * w_row_bytes + i * kTileBytes, kAuxDefault);
-    store_stage(0);
     __syncthreads();
 
     auto span_body = [&](const unsigned sp, auto last_c) {
@@ -215,10 +212,10 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
             constexpr bool kNextA = !kLast || (T + 1 < KS);
             const unsigned kt = kt0 + T;
             const unsigned cur = kt & 1u;
-            const u32x4 *const a_cur = smem + cur * Cfg::kBufU4;
-            const unsigned char *const a_cur_bytes = reinterpret_cast<const unsigned char *>(a_cur);
+            const u32x4 *const a_cur = smem + cur * Cfg::kDataU4;
+            const unsigned char *const a_cur_bytes = reinterpret_cast<const unsigned char *>(smem + 2 * Cfg::kDataU4 + cur * Cfg::kScaleU4);
             if constexpr (kNextA)
-                load_stage(kt + 1);
+                dma_stage(kt + 1, cur ^ 1u); // everybody left that buffer at the barrier that ended the previous step
             if constexpr (!kLast && T == KS - 1) { // next span's scale records: one step ahead is enough
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
@@ -249,9 +246,9 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
                 u32x4 flo[2], fhi[2];
                 int fsc[2];
                 auto read_frag = [&](int mt, int slot) {
-                    flo[slot] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4];
-                    fhi[slot] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + 1];
-                    fsc[slot] = (int)a_cur_bytes[a_scale_byte + mt * 16 * Cfg::kRowU4 * 16];
+                    flo[slot] = a_cur[a_frag_lo + mt * 16 * 8];
+                    fhi[slot] = a_cur[a_frag_hi + mt * 16 * 8];
+                    fsc[slot] = (int)a_cur_bytes[a_scale_byte + mt * 16 * 4];
                 };
                 read_frag(0, 0);
 #pragma unroll
@@ -271,9 +268,9 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const u32x4 lo = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4];
-                    const u32x4 hi = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + 1];
-                    const int ascale = (int)a_cur_bytes[a_scale_byte + mt * 16 * Cfg::kRowU4 * 16];
+                    const u32x4 lo = a_cur[a_frag_lo + mt * 16 * 8];
+                    const u32x4 hi = a_cur[a_frag_hi + mt * 16 * 8];
+                    const int ascale = (int)a_cur_bytes[a_scale_byte + mt * 16 * 4];
                     const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
@@ -282,10 +279,8 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
                             (int)srec[nt].d[T / 4], 0, ascale);
                 }
             }
-            if constexpr (kNextA) {
-                store_stage(cur ^ 1u);
+            if constexpr (kNextA)
                 __syncthreads();
-            }
             // Pin the step: left alone, LLVM sinks all MT*NTW*KS MFMAs of a span below its last barrier
             // and hoists every step's LDS traffic above them (hundreds of spilled VGPRs, no overlap).
             __builtin_amdgcn_sched_barrier(0);
