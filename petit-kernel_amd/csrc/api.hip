@@ -94,41 +94,88 @@ uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
 // SiLU-mul epilogue: a wave must hold the gate and the up tile of an output tile -> even n-tiles per wave
 bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0; }
 
+// M > 16: a cost model calibrated on the r01 sweeps (profiles/r01_tune_midm_*.json, r01_tune_bigm_*.json; microseconds
+// on MI355X, bf16 x NVFP4; the other families scale uniformly, which does not change the argmin much):
+//  * streaming kernel, MT m-tiles per workgroup, NT n-tiles per wave: every 16*MT-row block repeats the unpack and
+//    pulls its activation fragments once per n-tile: (0.5 + 2 MT/NT) e-7 us per weight fits MT = 1 / 2 / 4 at
+//    NT = 4 (1.0 / 1.5 / 2.5) and MT = 4 at NT = 2 (4.5 modelled, 5.2 measured);
+//  * tiled kernel: K/128 steps of t1(tile) each, times the number of rounds the grid needs on the chip (workgroups
+//    are dispatched dynamically, so rounds is fractional; two-per-CU residency buys ~14 %).
+// tools/check_heuristic.py replays it against every swept case.
+double stream_cost_us(const StreamShape &s, unsigned m, unsigned n, unsigned k, int num_cus) {
+    const double per_weight = (0.5 + 2.0 * s.mt / s.nt) * 1e-7; // unpack once per block + fragment loads per (m-tile, n-tile) pair
+    const unsigned blocks = (m + 16 * s.mt - 1) / (16 * s.mt);
+    const double wgs = (double)blocks * ((n / kTileN + s.nt * s.wn - 1) / (s.nt * s.wn));
+    // VALU-bound: a CU that holds two workgroups takes twice as long, one that holds none idles
+    const double rounds = (double)(((unsigned)wgs + num_cus - 1) / num_cus);
+    return 2.0 + blocks * (double)n * (double)k * per_weight * rounds * num_cus / wgs;
+}
+double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus) {
+    const StreamShape &s = e.shape;
+    const int acc = s.mt * s.nt; // accumulator tiles per wave: 8 = 64x128 / 128x64, 16 = 64x256 / 128x128
+    const bool split = e.a_type == kDataTypeFp16 && e.fmt == kFmtMx; // two MFMAs per fragment, two LDS images
+    double t1, resident;
+    if (split) {
+        t1 = s.mt == 4 && s.nt == 2 ? 1.14 : s.mt == 4 && s.nt == 4 ? 1.67 : s.mt == 8 && s.nt == 2 ? 3.0 : 0.19 * acc + 0.3;
+        resident = acc <= 8 && s.mt <= 4 ? 1.14 : 1.0;
+    } else {
+        t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
+           : s.mt == 8 && s.nt == 1 ? 0.94 : 0.09 * acc + 0.2;
+        if (e.fmt == kFmtMx)
+            t1 *= 0.82; // no group-scale multiplies in the unpack
+        resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
+    }
+    const unsigned per_wg = s.nt * s.wn;
+    const double wgs = (double)((m + 16 * s.mt - 1) / (16 * s.mt)) * (double)((n / kTileN + per_wg - 1) / per_wg);
+    double rounds = wgs / (num_cus * resident);
+    if (rounds < 1.0)
+        rounds = 1.0;
+    return 2.0 + (k / kTileK) * t1 * rounds;
+}
+
 const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k, bool need_pairs = false) {
     // Rules distilled from the MI355X sweeps (profiles/):
     //  * M <= 16: stage the activations through LDS (AM = smallest that holds M);
-    //  * what saturates HBM is bytes in flight: as many resident waves as the grid
-    //    allows, every wave with its whole ring outstanding -> pick the shape whose
-    //    wave count is closest to (but preferably above) 4 waves per SIMD;
-    //  * 5 <= M <= 16: two n-tiles per wave halve the activation traffic;
-    //  * larger M: more m-tiles per workgroup, capped by registers.
+    //  * M <= 4: what saturates HBM is bytes in flight: as many resident waves as the grid allows, every wave with
+    //    its whole ring outstanding -> the shape whose wave count is closest to (preferably above) 4 per SIMD;
+    //  * 5 <= M <= 16: the activation block every workgroup pulls through L2 starts to matter: two n-tiles per wave
+    //    (four when N is large), K split over 4 waves, one wave per SIMD is enough;
+    //  * M > 16: the cost model above picks between the streaming shapes (MT = 1 / 2 / 4) and the tiled kernel.
     const ArchInfo &arch = arch_info(current_device());
     const unsigned ntiles = n / kTileN;
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
-    if (m >= 48) { // MFMA-bound regime: the tiled kernel, 128-row tiles once M fills them -- provided its
-                   // grid fills the chip (it has no K split): at N = 8192 that needs M >= 256, below
-                   // that the streaming kernel with 4 m-tiles per workgroup is 2-3x faster (r01 sweeps)
-        const int want = m >= 96 ? 8 : 4;
-        const SolutionEntry *pick = nullptr;
-        unsigned pick_wgs = 0;
+    if (m > 16) {
+        const SolutionEntry *best = nullptr;
+        double best_us = 1e30;
         for (int i = 0; i < fam.count; ++i) {
             const SolutionEntry &e = fam.entries[i];
-            if (e.shape.am != kTiledAm || !entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
+            const StreamShape &s = e.shape;
+            if (!entry_fits(e, m, k) || s.am == kNativeAm || (need_pairs && !act_ok(e)))
                 continue; // (never the native-FP4 kernels: different accuracy class)
-            const unsigned per_wg = e.shape.nt * e.shape.wn;
-            const unsigned wgs = ((m + 16 * e.shape.mt - 1) / (16 * e.shape.mt)) * ((ntiles + per_wg - 1) / per_wg);
-            const bool fills = wgs * 4 >= arch.num_cus * 3, pick_fills = pick_wgs * 4 >= arch.num_cus * 3;
-            if (!pick || (fills && !pick_fills) ||
-                (fills == pick_fills && e.shape.mt == want && pick->shape.mt != want))
-                pick = &e, pick_wgs = wgs;
+            double us;
+            if (s.am == kTiledAm) {
+                us = tiled_cost_us(e, m, n, k, arch.num_cus);
+                us -= 0.001 * s.d; // deeper ring on a tie
+            } else {
+                if (s.am != 0 || s.wn != 1)
+                    continue;
+                us = stream_cost_us(s, m, n, k, arch.num_cus);
+                // the swept winners: WK = 4, fragments requested 2 tiles ahead
+                us *= 1.0 + 0.05 * (s.wk != 4) + 0.02 * (s.pa != 2);
+                if (nspans < (unsigned)s.wk)
+                    us *= (double)s.wk / nspans; // idle K waves
+            }
+            if (us < best_us)
+                best_us = us, best = &e;
         }
-        if (pick && (pick_wgs * 4 >= arch.num_cus * 3 || m > 256))
-            return pick;
+        if (best)
+            return best;
     }
-    const int want_mt = m <= 16 ? 1 : m <= 32 ? 2 : 4;
-    const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : m <= 16 ? 16 : 0;
-    const int want_nt = m <= 4 ? 1 : 2;
-    const double target_waves = (double)arch.num_cus * 4 * 4;
+    const int want_mt = 1;
+    const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16;
+    const bool mid = m > 4; // 5..16
+    const int want_nt = m <= 2 ? 1 : (mid && ntiles >= 4u * arch.num_cus) ? 4 : 4u * ntiles >= 5u * arch.num_cus ? 2 : 1;
+    const double target_waves = (double)arch.num_cus * (mid ? 4 : m > 2 ? 8 : 16);
     const SolutionEntry *best = nullptr;
     double best_score = -1e30;
     for (int i = 0; i < fam.count; ++i) {

@@ -103,6 +103,12 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
     // tuned ids are only meaningful on the arch they were measured on
     if (strcmp(arch_info(device).name, "gfx950") != 0)
         return 0;
+    static const bool disabled = [] { // $PETIT_AMD_NO_TUNED=1: heuristic only (tools/check_heuristic.py measures what that costs)
+        const char *e = getenv("PETIT_AMD_NO_TUNED");
+        return e && *e && *e != '0';
+    }();
+    if (disabled)
+        return 0;
     std::call_once(g_override_once, load_override);
     for (const TunedEntry &e : g_override)
         if (matches(e, a_type, b_type, m, n, k))
