@@ -275,3 +275,16 @@ def test_arch_table_rows_and_tune_file_override(tmp_path):
     tune.write_text(f"# a_type b_type n k m_lo m_hi solution\n{at} {bt} {n} {k} {lo} {lo} {other:x}\n")
     assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune)}, at, bt, lo, n, k) == other
     assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": ""}, at, bt, lo, n, k) == sol
+
+
+def test_heuristic_stays_close_to_the_measured_best():
+    """Where the arch table has no row the heuristic decides: replayed (table disabled) against every case of the
+    committed MI355X sweeps it must stay within 1.3x of the best measured solution, median within 1.05x."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "check_heuristic.py")], capture_output=True, text=True,
+                         check=True).stdout
+    m = re.search(r"slowdown vs best: median ([0-9.]+), p90 ([0-9.]+), max ([0-9.]+)", out)
+    assert m, out
+    median, p90, worst = (float(x) for x in m.groups())
+    assert median <= 1.05 and p90 <= 1.2 and worst <= 1.3, out
