@@ -120,7 +120,7 @@ double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k,
         resident = acc <= 8 && s.mt <= 4 ? 1.14 : 1.0;
     } else {
         t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
-           : s.mt == 8 && s.nt == 1 ? 0.94 : 0.09 * acc + 0.2;
+           : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97 : 0.09 * acc + 0.2;
         if (e.fmt == kFmtMx)
             t1 *= 0.82; // no group-scale multiplies in the unpack
         resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
@@ -170,6 +170,15 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         }
         if (best)
             return best;
+    }
+    if (m > 8 && ntiles >= 12u * arch.num_cus) {
+        // very wide N (gate_up): the 16 x 256 tiled shape shares one activation tile among 256 columns; the streaming
+        // kernel would pull the activations through L2 once per 32-64 columns (measured 52.9 vs 57.0 us at M = 16)
+        for (int i = 0; i < fam.count; ++i) {
+            const SolutionEntry &e = fam.entries[i];
+            if (e.shape.am == kTiledAm && e.shape.mt == 1 && e.shape.nt == 4 && entry_fits(e, m, k) && (!need_pairs || act_ok(e)))
+                return &e;
+        }
     }
     const int want_mt = 1;
     const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16;

@@ -9,6 +9,11 @@ for fam in "nv bf16" "nv f16" "mx bf16" "mx f16"; do
   python tools/tune.py --shapes $SH --ms 1,2,4,8,16 --fmt $1 --dtype $2 --out gpurun_out/${TAG}_tune_$1_$2.json > gpurun_out/${TAG}_tune_$1_$2.log 2>&1
   python tools/tune.py --shapes sq8192,qkv,gate_up,down --ms 32,64,128,256 --fmt $1 --dtype $2 --rotate-mb 640 --out gpurun_out/${TAG}_tune_midm_$1_$2.json > gpurun_out/${TAG}_tune_midm_$1_$2.log 2>&1
 done
+# very wide N at M = 16 / 32: the 16- and 32-row tiled shapes against the streaming kernel
+for fam in "nv bf16" "nv f16" "mx bf16" "mx f16"; do
+  set -- $fam
+  python tools/tune.py --shapes gate_up --ms 16,32 --fmt $1 --dtype $2 --out gpurun_out/${TAG}_tune_wideN_$1_$2.json > gpurun_out/${TAG}_tune_wideN_$1_$2.log 2>&1
+done
 # the reference's headline claim (README.md:27, "1.2x-2.2x over hipBLASLt bf16 for batch < 16"): the default pick next to the
 # vendor 16-bit GEMM on a dense weight of the same shape
 python tools/tune.py --shapes $SH --ms 1,4,8,16 --fmt nv --dtype bf16 --only-default --compare-dense --out gpurun_out/${TAG}_tune_vs_dense_nv_bf16.json > gpurun_out/${TAG}_tune_vs_dense_nv_bf16.log 2>&1
