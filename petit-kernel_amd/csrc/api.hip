@@ -102,8 +102,10 @@ bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0; }
 //  * tiled kernel: K/128 steps of t1(tile) each, times the number of rounds the grid needs on the chip (workgroups
 //    are dispatched dynamically, so rounds is fractional; two-per-CU residency buys ~14 %).
 // tools/check_heuristic.py replays it against every swept case.
-double stream_cost_us(const StreamShape &s, unsigned m, unsigned n, unsigned k, int num_cus) {
-    const double per_weight = (0.5 + 2.0 * s.mt / s.nt) * 1e-7; // unpack once per block + fragment loads per (m-tile, n-tile) pair
+double stream_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus) {
+    const StreamShape &s = e.shape;
+    const bool split = e.a_type == kDataTypeFp16 && e.fmt == kFmtMx; // hi/lo activations: two MFMAs and two fragments per word
+    const double per_weight = (0.5 + 2.0 * s.mt / s.nt) * (split ? 1.5e-7 : 1e-7); // unpack once per block + fragment loads per (m-tile, n-tile) pair
     const unsigned blocks = (m + 16 * s.mt - 1) / (16 * s.mt);
     const double wgs = (double)blocks * ((n / kTileN + s.nt * s.wn - 1) / (s.nt * s.wn));
     // VALU-bound: a CU that holds two workgroups takes twice as long, one that holds none idles
@@ -122,7 +124,7 @@ double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k,
         t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
            : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97 : 0.09 * acc + 0.2;
         if (e.fmt == kFmtMx)
-            t1 *= 0.82; // no group-scale multiplies in the unpack
+            t1 *= 0.75; // no group-scale multiplies in the unpack
         resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
     }
     const unsigned per_wg = s.nt * s.wn;
@@ -159,7 +161,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
             } else {
                 if (s.am != 0 || s.wn != 1)
                     continue;
-                us = stream_cost_us(s, m, n, k, arch.num_cus);
+                us = stream_cost_us(e, m, n, k, arch.num_cus);
                 // the swept winners: WK = 4, fragments requested 2 tiles ahead
                 us *= 1.0 + 0.05 * (s.wk != 4) + 0.02 * (s.pa != 2);
                 if (nspans < (unsigned)s.wk)
