@@ -4,7 +4,7 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+Headline (the fields the driver reads; BASELINE.json configs[1], the configuration the metric is quoted on):
     one step = ONE call of the hot path, C[1,8192] = A[1,8192] . dequant(W[8192,8192])^T * gs,
     bf16 activations x NVFP4 weights (e4m3 scales, group 16), through the drop-in Python
     surface petit_kernel.mul_nvfp4_a16(..., solution_id=-1) -> C ABI -> HIP kernel.
@@ -14,6 +14,15 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
     Infinity Cache -- the reference's own benchmark reuses a single buffer
     (tools/benchmarks/matmul/rocm/matmul_petit.cc:116-132), which on MI355X would measure the
     cache, not HBM.
+    The K steps are one HIP-graph replay, bracketed by barrier + synchronize on both sides as the
+    contract asks; that bracketed region is repeated `--repeats` times (default 11) and the MEDIAN is
+    reported, so a short run (--steps 20 = 0.17 ms) is not a single sample.
+
+The rest of the metric ("TFLOPS + achieved HBM GB/s, M in {1,8,16,512}, Llama-70B shapes") is in `cells`
+(rank 0, N = 1 only): every (M, shape) of {1, 8, 16, 512} x {qkv, o, gate_up, down} for bf16 x NVFP4 through
+solution_id = -1, plus at M = 512 the opt-in native-FP4 path (bf16 x MXFP4) and an explicit hipBLASLt bf16 GEMM
+on a dense weight of the same shape (the reference's comparator, tools/benchmarks/matmul.py:92-165,
+matmul/rocm/matmul_hipblaslt.cc:103-123), all measured in this process with tools/benchlib.py.
 
 Multi-GPU: the op is a single-GPU primitive with no exchange step:
 "replicas only" -- every rank runs the same workload on its own weights, no data-path
@@ -24,6 +33,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,6 +43,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT / "petit-kernel_amd"))
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
 
 import numpy as np
 import torch
@@ -60,7 +71,7 @@ def make_inputs(seed: int, copies: int):
     return a, gs, qs, ss
 
 
-def cpu_baseline(a, gs, q, s, budget_s: float = 12.0):
+def cpu_baseline(a, gs, q, s, budget_s: float = 10.0):
     """The oracle ("port" of tests/ops/test_fp4_gemm_quark.py:9-24: LUT dequant + f32 matmul)
     timed on this box's host cores on the SAME workload (one full M=1 8192x8192 call per rep)."""
     from oracle import oracle as O
@@ -86,13 +97,116 @@ def cpu_baseline(a, gs, q, s, budget_s: float = 12.0):
     }
 
 
+def measure_cells(dev, stream, budget_s: float) -> dict:
+    """The whole metric: M in {1, 8, 16, 512} x the four Llama-3-70B linears, bf16 x NVFP4 through solution_id = -1;
+    at M = 512 also the native-FP4 kernels (bf16 x MXFP4, opt-in accuracy class) and hipBLASLt bf16 on a dense weight."""
+    import benchlib as BL
+    from petit_kernel import _lib
+    t0 = time.time()
+    cells, notes = [], []
+    auto = _lib.PETIT_SOLUTION_AUTO
+    for shape in ("qkv", "o", "gate_up", "down"):
+        n, k = BL.LLAMA70B[shape]
+        w = BL.Weights("nv", n, k, 1280, dev)
+        for m in (1, 8, 16, 512):
+            if time.time() - t0 > budget_s:
+                notes.append(f"time budget reached before {shape} M={m}")
+                break
+            g = BL.Gemm(w, m, torch.bfloat16, dev)
+            sid = g.default_solution()
+            r = g.time(auto, stream, reps=7)
+            hbm = m <= 16
+            cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x nvfp4", "us": round(r["us"], 3),
+                          "us_min": round(r["us_min"], 3), "GB/s": round(r["gbs"], 1), "TFLOPS": round(r["tflops"], 2),
+                          "bound": "hbm" if hbm else "mfma",
+                          "frac": round(r["gbs"] / BL.HBM_PEAK_GBS if hbm else r["tflops"] / BL.BF16_PEAK_TFLOPS, 4),
+                          "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"})
+        del w
+        torch.cuda.empty_cache()
+        if time.time() - t0 > budget_s:
+            continue
+        # M = 512: native-FP4 path (MXFP4 weights; activations quantised on the fly) and the vendor dense GEMM
+        m = 512
+        wm = BL.Weights("mx", n, k, 1280, dev)
+        gm = BL.Gemm(wm, m, torch.bfloat16, dev)
+        sid = gm.default_solution()
+        r = gm.time(auto, stream, reps=5)
+        cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x mxfp4", "us": round(r["us"], 3),
+                      "us_min": round(r["us_min"], 3), "GB/s": round(r["gbs"], 1), "TFLOPS": round(r["tflops"], 2),
+                      "bound": "mfma", "frac": round(r["tflops"] / BL.BF16_PEAK_TFLOPS, 4),
+                      "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"})
+        _lib.lib.petit_enable_native_fp4(1)
+        try:
+            best = None
+            for nsid in [s for s in gm.solutions() if (s >> 48) & 0xF == 9]:
+                for sk in (1, 2):
+                    if sk > 1 and n * m > 8192 * 512 * 2:
+                        continue   # K split only pays where the plain grid under-fills the chip
+                    cand = (nsid & ~(0xF << 60)) | (sk << 60)
+                    rr = gm.time(cand, stream, reps=3, launches=10)
+                    if best is None or rr["us"] < best[1]["us"]:
+                        best = (cand, rr)
+            if best:
+                cand, rr = best
+                rr = gm.time(cand, stream, reps=5)
+                fp4x4 = (cand >> 32) & 0x4 != 0
+                peak = BL.FP4_PEAK_TFLOPS if fp4x4 else BL.FP8_PEAK_TFLOPS
+                cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x mxfp4 native (opt-in)",
+                              "us": round(rr["us"], 3), "us_min": round(rr["us_min"], 3), "TFLOPS": round(rr["tflops"], 2),
+                              "bound": "mfma", "peak_TFLOPS": peak, "frac": round(rr["tflops"] / peak, 4),
+                              "frac_of_fp4_peak": round(rr["tflops"] / BL.FP4_PEAK_TFLOPS, 4),
+                              "solution": f"0x{cand:x} {_lib.describe_solution(cand)}",
+                              "note": "both launches (activation quantiser + GEMM) timed"})
+        finally:
+            _lib.lib.petit_enable_native_fp4(0)
+        del wm, gm
+        torch.cuda.empty_cache()
+        try:
+            hb = BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev)
+            hb.check()
+            rr = hb.time(stream, reps=5)
+            cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x bf16 dense, hipBLASLt (comparator)",
+                          "us": round(rr["us"], 3), "us_min": round(rr["us_min"], 3), "TFLOPS": round(rr["tflops"], 2),
+                          "bound": "mfma", "frac": round(rr["tflops"] / BL.BF16_PEAK_TFLOPS, 4),
+                          "solution": "hipblasLtMatmul, HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm, 32 MB workspace",
+                          "launch": rr["launch"]})
+            hb.close()
+            del hb
+        except Exception as exc:  # noqa: BLE001 -- the comparator must never take the bench down
+            notes.append(f"hipBLASLt comparator failed on {shape}: {exc}")
+        torch.cuda.empty_cache()
+    return {"cells": cells, "cells_notes": notes, "cells_seconds": round(time.time() - t0, 1),
+            "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, "
+                            "median of 5-7 replays; frac = GB/s / 8000 (M <= 16) or TFLOPS / 2500 (M = 512; native: / its MFMA-rate peak)"}
+
+
+def host_overhead(step, n_calls: int = 3000) -> dict:
+    """Eager host cost per call of the Python surface (graph replay hides it): wall time of n_calls back-to-back
+    enqueues divided by n_calls, while the GPU queue is never empty (so it is the HOST that is timed when the
+    kernel is shorter than the call; otherwise the kernel time shows)."""
+    for i in range(200):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_calls):
+        step(i)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return {"enqueue_us_per_call": (t1 - t0) / n_calls * 1e6, "wall_us_per_call_incl_drain": (t2 - t0) / n_calls * 1e6,
+            "calls": n_calls}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=1000)
+    ap.add_argument("--repeats", type=int, default=11, help="timed K-step regions; the median is reported")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cells", action="store_true", help="headline only (skip the M x shape table)")
+    ap.add_argument("--cells-budget-s", type=float, default=150.0)
     ap.add_argument("--rotate-mb", type=int, default=1280,
                     help="rotate over at least this many MB of distinct weights; measured on MI355X: per-launch time "
                          "keeps rising until ~1.3 GB (8.3 us at 40 MB, 8.7 at 320 MB, 9.2 at >= 1.3 GB), i.e. the 256 MB "
@@ -147,6 +261,7 @@ def main() -> None:
 
     stream = torch.cuda.Stream(dev)
     warmup_done = 0
+    region_ms, region_wall_ms = [], []
     with torch.cuda.stream(stream):
         out = step(0)                              # first call: module load, arch table
         stream.synchronize()
@@ -160,42 +275,46 @@ def main() -> None:
             except Exception as exc:               # capture unsupported: time eager launches
                 print(f"[bench] graph capture failed ({exc}); timing eager launches", file=sys.stderr)
                 graph = None
-        # untimed warm-up: the same steps, so clocks and caches are in steady state.  At least
-        # ~20 ms of it whatever --warmup says: measured on MI355X, a 400-step replay timed after
-        # only 400 warm-up steps reads 10.4 us/step, after 2000 warm-up steps 9.2 (DVFS ramp).
-        min_warm = max(args.warmup, 2000)
-        if graph is not None:
-            while warmup_done < min_warm:
+        # untimed warm-up: the same steps, so clocks and caches are in steady state: --warmup steps, and at least
+        # ~20 ms of them (measured on MI355X: a 400-step replay timed after only 400 warm-up steps reads 10.4 us/step,
+        # after 2000 warm-up steps 9.2 -- DVFS ramp)
+        t_w = time.perf_counter()
+        while warmup_done < args.warmup or time.perf_counter() - t_w < 0.03:
+            if graph is not None:
                 graph.replay()
-                warmup_done += args.steps
-        else:
-            for i in range(args.warmup):
-                out = step(i)
-            warmup_done = args.warmup
-        stream.synchronize()
+            else:
+                for i in range(args.steps):
+                    out = step(i)
+            warmup_done += args.steps
+            stream.synchronize()
 
-        # events are recorded on the stream the kernels run on
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        e0.record(stream)
-        if graph is not None:
-            graph.replay()                         # exactly args.steps steps
-        else:
-            for i in range(args.steps):
-                out = step(i)
-        e1.record(stream)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        barrier()
-    ev_ms = e0.elapsed_time(e1)
-
-    # whole-job time = slowest rank (petit_kernel/replicas.py; covered on CPU with gloo)
+        # events are recorded on the stream the kernels run on; every timed region is exactly --steps steps,
+        # bracketed by barrier + synchronize on both sides
+        for _ in range(max(1, args.repeats)):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record(stream)
+            if graph is not None:
+                graph.replay()                         # exactly args.steps steps
+            else:
+                for i in range(args.steps):
+                    out = step(i)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            barrier()
+            region_ms.append(e0.elapsed_time(e1))
+            region_wall_ms.append(wall * 1e3)
+    # median region; whole-job time = slowest rank (petit_kernel/replicas.py; covered on CPU with gloo)
+    order = sorted(range(len(region_ms)), key=lambda i: region_ms[i])
+    mid = order[len(order) // 2]
+    ev_ms, wall_ms = region_ms[mid], region_wall_ms[mid]
     from petit_kernel import replicas
     ev_ms_max = replicas.max_over_ranks(ev_ms, dev)
-    wall_ms_max = replicas.max_over_ranks(wall * 1e3, dev)
+    wall_ms_max = replicas.max_over_ranks(wall_ms, dev)
     ms_per_step = ev_ms_max / args.steps
 
     # sanity: the timed kernel really computes the GEMM (checked against the oracle in smoke()/tests)
@@ -204,16 +323,16 @@ def main() -> None:
     if rank == 0:
         # HBM bytes per launch from the PMC passes of the same command (tools/collect_profiles.sh,
         # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); rocprofv3 cannot run inside this process
-        traffic = None
+        traffic, traffic_src = None, None
         for cand in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
             try:
                 traffic = json.loads(cand.read_text())["traffic_bytes_per_launch"]
+                traffic_src = f"from profiles/{cand.name} (separate rocprofv3 --pmc passes of this command; not measured in this run)"
                 break
             except Exception:
                 pass
         per_gpu_gbs = bytes_per_step / (ms_per_step * 1e-3) / 1e9
         from petit_kernel import _lib
-        import ctypes as C
         hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
         sid = _lib.lib.petit_gemm_default_solution(C.byref(hints), M, N, K)
         line = {
@@ -222,7 +341,7 @@ def main() -> None:
             "unit": "GB/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": warmup_done,
+            "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
@@ -232,9 +351,13 @@ def main() -> None:
             "config": {"workload": "M=1 N=8192 K=8192 bf16 x nvfp4 (e4m3 scales, g=16), one mul_nvfp4_a16 call per step",
                        "weights_rotated_over_copies": copies, "parallelism": f"replicas x{world} (no data-path collective)",
                        "launch": "hip graph replay" if graph is not None else "eager",
-                       "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"},
+                       "solution": f"0x{sid:x} {_lib.describe_solution(sid)}",
+                       "timed_regions": len(region_ms), "statistic": "median region",
+                       "warmup_steps_run": warmup_done},
             "tflops": 2.0 * M * N * K / (ms_per_step * 1e-3) / 1e12 * world,
             "wall_ms_per_step": wall_ms_max / args.steps,
+            "ms_per_step_regions": {"min": min(region_ms) / args.steps, "median": ev_ms / args.steps,
+                                    "max": max(region_ms) / args.steps},
             "roofline": {
                 "bound": "hbm",
                 "achieved": per_gpu_gbs,
@@ -242,11 +365,31 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": per_gpu_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "petit_amd::gemm_stream_kernel",
                 "bytes_per_launch": bytes_per_step,
                 "us_per_launch": ms_per_step * 1e3,
             },
         }
+        if world == 1:
+            with torch.cuda.stream(stream):
+                line["host_us_per_call"] = {"ctypes": host_overhead(step)}
+                try:
+                    from petit_kernel import compiled
+                    if compiled.available():
+                        def cstep(i):
+                            b, sp = packed[i % copies]
+                            return compiled.mul_nvfp4_a16(a_d, b, sp, gs_d, M, N, K, -1)
+                        line["host_us_per_call"]["compiled_torch_library_op"] = host_overhead(cstep)
+                except Exception as exc:  # noqa: BLE001
+                    line["host_us_per_call"]["compiled_torch_library_op"] = f"unavailable: {exc}"
+        del packed
+        torch.cuda.empty_cache()
+        if world == 1 and not args.no_cells:
+            try:
+                line.update(measure_cells(dev, stream, args.cells_budget_s))
+            except Exception as exc:  # noqa: BLE001 -- the table must never cost the headline line
+                line["cells_error"] = repr(exc)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a, gs, qs[0], ss[0])
         print(json.dumps(line), flush=True)

@@ -15,8 +15,10 @@
  * petit_set_workspace().  All work is enqueued on `stream` (a hipStream_t);
  * nothing synchronises the host, so every call is HIP-graph capturable.
  * Thread safety: all entry points may be called concurrently from several
- * host threads; petit_set_workspace() is per-device state and must not race
- * with GEMM calls on the same device.
+ * host threads and streams; kernels that need scratch memory take it per call
+ * (petit_gemm_*_ws) or from the per-device registered workspace, which serves
+ * ONE stream at a time (see "Scratch memory" below); petit_set_workspace()
+ * itself must not race with GEMM calls on the same device.
  */
 #ifndef PETIT_AMD_H_
 #define PETIT_AMD_H_
@@ -184,14 +186,40 @@ int petit_repack_nvfp4_scales_host(unsigned *out_scales, const unsigned *scales,
 int petit_repack_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan);
 
 /*
- * Optional fp32 scratch for kernels that split K across workgroups.  The
- * reference API has no workspace argument (SURVEY.md section 8b "Ownership");
- * kernels that need one are only selected when a workspace of sufficient
- * size has been registered for the current device.  Pass (NULL, 0) to
- * unregister.  The memory stays owned by the caller.
+ * Scratch memory ("workspace").  The reference API has no workspace argument (SURVEY.md section 8b "Ownership"); two
+ * kinds of kernels here need device scratch: those that split K across workgroups (fp32 partial slabs, summed in a
+ * fixed order by a second pass: deterministic, no float atomics) and the native-FP4 kernels (quantised activations).
+ * petit_gemm_workspace_bytes() says how much a call needs; 0 for most kernels.
+ *
+ * Per call (preferred; the only form that is safe with several streams or concurrently running graphs):
+ *   petit_gemm_*_ws(..., epilogue, workspace, workspace_bytes, stream) -- caller-owned device memory that must stay
+ *   untouched until the work enqueued on `stream` by this call has finished (stream-ordered allocators give exactly
+ *   that).  With PETIT_SOLUTION_AUTO a missing / too small workspace selects a kernel that needs none; with an
+ *   explicit id that needs scratch it is PETIT_ERROR_KERNEL_SHAPE (none) / PETIT_ERROR_BAD_ARGUMENT (too small).
+ *   epilogue may be NULL.  The Python layer allocates this per call from torch's caching allocator.
+ * Registered (legacy convenience for single-stream programs): petit_set_workspace(ptr, bytes) per device; used by the
+ *   entry points without a workspace argument.  One buffer cannot serve two streams at once: it binds to the first
+ *   stream that uses it and calls from any other stream are refused with PETIT_ERROR_BAD_ARGUMENT (explicit ids) or
+ *   fall back to a kernel without scratch (AUTO) until petit_set_workspace is called again.  Pass (NULL, 0) to
+ *   unregister.  The memory stays owned by the caller.
  */
+int petit_gemm_fp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b,
+                                const unsigned *scales, const float *global_scale,
+                                unsigned m, unsigned n, unsigned k,
+                                const petit_solution_hints *hints, uint64_t solution_id,
+                                const petit_epilogue *epilogue, void *workspace, uint64_t workspace_bytes, void *stream);
+int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b,
+                                  const unsigned *scales, const float *global_scale,
+                                  unsigned m, unsigned n, unsigned k,
+                                  const petit_solution_hints *hints, uint64_t solution_id,
+                                  const petit_epilogue *epilogue, void *workspace, uint64_t workspace_bytes, void *stream);
+/* Bytes of scratch the call (hints, m, n, k, solution_id) uses when it is given enough; solution_id may be
+ * PETIT_SOLUTION_AUTO (the arch table may name a K-split kernel for the shape).  0: none needed. */
+uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
+                                    uint64_t solution_id);
 int petit_set_workspace(void *device_ptr, uint64_t bytes);
-/* Bytes a given solution needs for (m, n); 0 for solutions without split-K. */
+/* fp32-slab bytes the split-K nibble of an id implies for (m, n) (kept for round-1 callers; prefer
+ * petit_gemm_workspace_bytes, which also covers the native kernels). */
 uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
 
 /*

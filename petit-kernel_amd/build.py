@@ -20,7 +20,7 @@ CSRC = ROOT / "csrc"
 OBJ = ROOT / "build"
 LIB = ROOT / "lib" / "libpetit_amd.so"
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-fno-gpu-rdc", "-DNDEBUG"]
 
 

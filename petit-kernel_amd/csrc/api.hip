@@ -6,9 +6,8 @@
 //   fp4/algo_chooser.cc:14-132        GemmGetSolutions, ChooseDefaultFp4Fp16Solution
 //   fp4/solution_map.cc, fp4/gen_solution_list.cc   (build-time kernel list)
 // The reference scans a 234-entry map on every call with solution_id = -1
-// (algo_chooser.cc:116-126); here the choice is a handful of integer compares
-// against the arch table (hal.h) and the table lookup is a linear scan over
-// < 20 entries of one (dtype, format) family.
+// (algo_chooser.cc:116-126); here the choice is made once per (thread, problem) -- arch table (hal.h), else the
+// cost model over the family's kernels -- and then served from a thread-local cache (choose_auto).
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -68,11 +67,19 @@ bool entry_fits(const SolutionEntry &e, unsigned m, unsigned k) {
     return e.shape.ks == span_tiles_for_k(k) && (e.shape.am <= 0 || m <= (unsigned)am_rows(e.shape.am));
 }
 
-// Per-device registered split-K workspace.
+// Scratch memory.  A call that needs scratch (fp32 slabs of a cross-workgroup K split, the quantised activations of the
+// native-FP4 path) takes it, in this order, from
+//   1. the per-call workspace handed to petit_gemm_*_ws (caller-owned, stream-ordered by construction: what the Python
+//      layer does with torch's caching allocator, and what concurrent streams / graphs must use);
+//   2. the workspace registered per device with petit_set_workspace.  One buffer cannot serve two streams at once, so it
+//      BINDS to the first stream that uses it; a call from any other stream is refused (PETIT_ERROR_BAD_ARGUMENT) until
+//      petit_set_workspace is called again -- never a silent race.
 constexpr int kMaxDevices = 64;
 struct Workspace {
     std::atomic<void *> ptr{nullptr};
     std::atomic<uint64_t> bytes{0};
+    std::atomic<uintptr_t> stream{kUnbound};
+    static constexpr uintptr_t kUnbound = ~(uintptr_t)0;
 };
 Workspace g_workspace[kMaxDevices];
 
@@ -85,6 +92,27 @@ int current_device() {
 
 uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
     return splitk > 1 ? (uint64_t)splitk * m * n * sizeof(float) : 0;
+}
+// bytes of scratch a (kernel, split) needs for (m, n, k): [native: quantised activations, 256-B aligned][slabs]
+uint64_t workspace_need(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k) {
+    const uint64_t slabs = splitk_bytes(splitk, m, n);
+    if (e.shape.am == kNativeAm)
+        return slabs ? native_ws_aligned(m, k) + slabs : native_ws_bytes(m, k);
+    return slabs;
+}
+// the registered workspace of `dev` for a call on `stream`: pointer, or nullptr (too small / none / *busy = other stream)
+void *registered_workspace(int dev, void *stream, uint64_t need, bool *busy) {
+    Workspace &ws = g_workspace[dev];
+    void *ptr = ws.ptr.load();
+    *busy = false;
+    if (!ptr || ws.bytes.load() < need)
+        return nullptr;
+    uintptr_t expect = Workspace::kUnbound;
+    if (!ws.stream.compare_exchange_strong(expect, (uintptr_t)stream) && expect != (uintptr_t)stream) {
+        *busy = true;
+        return nullptr;
+    }
+    return ptr;
 }
 
 // Default choice when the arch table has no entry: pick the shape whose
@@ -250,16 +278,68 @@ bool native_enabled() {
     return v != 0;
 }
 
+// What solution_id = -1 resolves to for (device, dtypes, act, m, n, k): arch table first, heuristic second; NEVER a
+// native-FP4 kernel (different accuracy class: a tune file that lists one is ignored for AUTO).  The choice is a pure
+// function of its key (the tables are immutable after static init), so every thread keeps a small direct-mapped
+// cache: the eager decode path pays a hash and a compare per call, not the table scans and the cost model.
+struct AutoChoice {
+    const SolutionEntry *entry;
+    unsigned splitk;
+};
+AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k) {
+    struct Slot {
+        uint64_t key0, key1;
+        AutoChoice val;
+    };
+    constexpr int kSlots = 64;
+    static thread_local Slot cache[kSlots] = {};
+    const uint64_t key0 = ((uint64_t)m << 32) | n;
+    const uint64_t key1 = ((uint64_t)k << 32) | ((uint64_t)(dev & 0xff) << 16) | ((uint64_t)(a_type & 0xf) << 8) |
+                          ((uint64_t)(b_type & 0xf) << 4) | (act ? 2u : 0u) | 1u; // bit 0: slot in use
+    Slot &slot = cache[(key0 * 0x9E3779B97F4A7C15ull ^ key1 * 0xC2B2AE3D27D4EB4Full) >> 58];
+    if (slot.key0 == key0 && slot.key1 == key1)
+        return slot.val;
+    AutoChoice c{nullptr, 1};
+    const uint64_t tuned = tuned_solution(dev, a_type, b_type, m, n, k);
+    if (tuned) {
+        c.entry = find_entry(fam, tuned);
+        c.splitk = solution_splitk(tuned);
+        if (c.entry && (c.entry->shape.am == kNativeAm || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
+                        (act && (!act_ok(*c.entry) || c.splitk != 1))))
+            c.entry = nullptr;
+    }
+    if (!c.entry) {
+        c.entry = heuristic(fam, m, n, k, act);
+        c.splitk = 1;
+    }
+    slot = Slot{key0, key1, c};
+    return c;
+}
+
+// An explicit id -> table entry.  The element_b nibble is forced to the entry point's format first, as the reference
+// does (gemm_fp4_fp16_grid.cc:79-95): ids enumerated with b_type = FP4_E2M1 (what get_fp4_solutions(m, n, k, a, c)
+// returns) therefore work with mul_mxfp4_a16; the block-floating-point staged kernels, which only exist for
+// bf16 x NVFP4, map to their plain staged twins.
+const SolutionEntry *find_explicit(const Family &fam, uint64_t id) {
+    id = (id & ~((uint64_t)0xf << 28)) | ((uint64_t)fam.elem_b << 28);
+    const SolutionEntry *e = find_entry(fam, id);
+    const unsigned am = (unsigned)(id >> 48) & 0xf;
+    if (!e && fam.elem_b == kElemBMxFp4 && am >= 5 && am <= 7)
+        e = find_entry(fam, (id & ~((uint64_t)0xf << 48)) | ((uint64_t)(am - 4) << 48));
+    return e;
+}
+
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
               const float *global_scale, unsigned m, unsigned n, unsigned k,
-              const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue, void *stream) {
+              const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
+              void *call_ws, uint64_t call_ws_bytes, void *stream) {
     if (epilogue && ((epilogue->activation != PETIT_ACTIVATION_NONE && epilogue->activation != PETIT_ACTIVATION_SILU_MUL) ||
                      epilogue->reserved != 0))
         return kErrBadArgument; // reject what a newer caller might ask for
     const bool act = epilogue && epilogue->activation == PETIT_ACTIVATION_SILU_MUL;
     if (m == 0 || n == 0 || k == 0)
         return kOk; // gemm_fp4_fp16_grid.cc:42-44
-    if (!hints || !c || !a || !b || !scales || !global_scale)
+    if (!hints || !c || !a || !b || !scales || !global_scale || (!call_ws && call_ws_bytes))
         return kErrBadArgument;
     if (hints->c_type != hints->a_type)
         return kErrKernelShape;
@@ -275,24 +355,17 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     if ((uint64_t)k * 16 * 4 * 2 >= (1ull << 31) || (uint64_t)k * 64 * 4 >= (1ull << 31))
         return kErrProblemShape;
 
+    const int dev = current_device();
+    const bool is_auto = solution_id == PETIT_SOLUTION_AUTO;
     const SolutionEntry *entry = nullptr;
     unsigned splitk = 1;
-    if (solution_id == PETIT_SOLUTION_AUTO) {
-        uint64_t tuned = tuned_solution(current_device(), hints->a_type, b_type, m, n, k);
-        if (tuned) {
-            entry = find_entry(fam, tuned);
-            splitk = solution_splitk(tuned);
-        }
-        if (entry && (!entry_fits(*entry, m, k) || (act && (!act_ok(*entry) || splitk != 1))))
-            entry = nullptr;
-        if (!entry) {
-            entry = heuristic(fam, m, n, k, act);
-            splitk = 1;
-        }
+    if (is_auto) {
+        const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k);
+        entry = ch.entry, splitk = ch.splitk;
         if (!entry)
             return kErrKernelShape;
     } else {
-        entry = find_entry(fam, solution_id);
+        entry = find_explicit(fam, solution_id);
         if (!entry)
             return kErrKernelShape;
         if (!entry_fits(*entry, m, k))
@@ -309,22 +382,28 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     args.m = m, args.n = n, args.k = k;
     args.bias = epilogue ? epilogue->bias : nullptr;
     args.act = act ? 1u : 0u;
-    if (entry->shape.am == kNativeAm) {
-        Workspace &ws = g_workspace[current_device()];
-        if (ws.ptr.load() == nullptr || ws.bytes.load() < native_ws_bytes(m, k))
-            return kErrKernelShape; // needs petit_set_workspace(>= petit_native_workspace_bytes(m, k))
-        args.workspace = (float *)ws.ptr.load();
-    }
-    if (splitk > 1) {
-        Workspace &ws = g_workspace[current_device()];
-        const uint64_t need = splitk_bytes(splitk, m, n);
-        if (ws.ptr.load() == nullptr || ws.bytes.load() < need) {
-            if (solution_id != PETIT_SOLUTION_AUTO)
-                return kErrKernelShape; // explicit id that needs a workspace nobody registered
-            splitk = 1;                 // tuned pick without workspace: fall back in-family
+    uint64_t need = workspace_need(*entry, splitk, m, n, k);
+    if (need) {
+        void *ws = nullptr;
+        if (call_ws) {
+            if (call_ws_bytes < need && !is_auto)
+                return kErrBadArgument; // too small for the kernel the caller named
+            ws = call_ws_bytes >= need ? call_ws : nullptr;
         } else {
-            args.workspace = (float *)ws.ptr.load();
+            bool busy = false;
+            ws = registered_workspace(dev, stream, need, &busy);
+            if (busy && !is_auto)
+                return kErrBadArgument; // the registered workspace is bound to another stream: pass one per call
         }
+        if (!ws) {
+            if (!is_auto)
+                return kErrKernelShape; // explicit id that needs scratch nobody provided
+            splitk = 1;                 // AUTO without scratch: same kernel, no cross-workgroup K split
+            need = workspace_need(*entry, 1, m, n, k);
+            if (need)
+                return kErrKernelShape; // (unreachable: AUTO never picks a native kernel)
+        }
+        args.workspace = (float *)ws;
     }
     return entry->launch(args, splitk, (hipStream_t)stream);
 }
@@ -339,28 +418,59 @@ extern "C" {
 int petit_gemm_fp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                              const float *global_scale, unsigned m, unsigned n, unsigned k,
                              const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
-    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, stream);
+    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, nullptr, 0, stream);
 }
 
 int petit_gemm_fp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                 const float *global_scale, unsigned m, unsigned n, unsigned k,
                                 const petit_solution_hints *hints, uint64_t solution_id,
                                 const petit_epilogue *epilogue, void *stream) {
-    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, stream);
+    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, nullptr, 0, stream);
+}
+
+int petit_gemm_fp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+                                const float *global_scale, unsigned m, unsigned n, unsigned k,
+                                const petit_solution_hints *hints, uint64_t solution_id,
+                                const petit_epilogue *epilogue, void *workspace, uint64_t workspace_bytes, void *stream) {
+    return gemm_impl(kDataTypeFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, workspace,
+                     workspace_bytes, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                const float *global_scale, unsigned m, unsigned n, unsigned k,
                                const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
-    // the reference forces element_b = MxFp4 into the id (gemm_fp4_fp16_grid.cc:79-95)
-    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, stream);
+    // the reference forces element_b = MxFp4 into the id (gemm_fp4_fp16_grid.cc:79-95): find_explicit does the same
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, nullptr, 0, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                   const float *global_scale, unsigned m, unsigned n, unsigned k,
                                   const petit_solution_hints *hints, uint64_t solution_id,
                                   const petit_epilogue *epilogue, void *stream) {
-    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, stream);
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, nullptr, 0, stream);
+}
+
+int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
+                                  const float *global_scale, unsigned m, unsigned n, unsigned k,
+                                  const petit_solution_hints *hints, uint64_t solution_id,
+                                  const petit_epilogue *epilogue, void *workspace, uint64_t workspace_bytes, void *stream) {
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, workspace,
+                     workspace_bytes, stream);
+}
+
+uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
+                                    uint64_t solution_id) {
+    Family fam;
+    if (!hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) ||
+        m == 0)
+        return 0;
+    if (solution_id == PETIT_SOLUTION_AUTO) {
+        const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, false, m, n, k);
+        return ch.entry ? workspace_need(*ch.entry, ch.splitk, m, n, k) : 0;
+    }
+    const SolutionEntry *e = find_explicit(fam, solution_id);
+    const unsigned splitk = solution_splitk(solution_id);
+    return e && splitk ? workspace_need(*e, splitk, m, n, k) : 0;
 }
 
 int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
@@ -392,14 +502,8 @@ uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned
     if (!hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) ||
         !shape_ok(n, k) || m == 0)
         return 0;
-    uint64_t tuned = tuned_solution(current_device(), hints->a_type, hints->b_type, m, n, k);
-    if (tuned) {
-        const SolutionEntry *e = find_entry(fam, tuned);
-        if (e && entry_fits(*e, m, k))
-            return tuned;
-    }
-    const SolutionEntry *e = heuristic(fam, m, n, k);
-    return e ? entry_id(fam, *e) : 0;
+    const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, false, m, n, k);
+    return ch.entry ? make_solution_id(ch.entry->shape, fam.elem_b, entry_mfma(fam, *ch.entry), ch.splitk) : 0;
 }
 
 int petit_repack_nvfp4_weights(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan,
@@ -441,12 +545,13 @@ int petit_set_workspace(void *device_ptr, uint64_t bytes) {
     Workspace &ws = g_workspace[current_device()];
     ws.bytes.store(0);
     ws.ptr.store(device_ptr);
+    ws.stream.store(Workspace::kUnbound); // binds again to the first stream that uses it
     ws.bytes.store(device_ptr ? bytes : 0);
     return kOk;
 }
 
 uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n) {
-    return splitk_bytes(solution_splitk(solution_id), m, n);
+    return splitk_bytes(solution_splitk(solution_id), m, n); // (split-K slabs only: see petit_gemm_workspace_bytes)
 }
 
 int petit_enable_native_fp4(int enable) {

@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 enum : int { kFmtNv = 0, kFmtMx = 1 };
 

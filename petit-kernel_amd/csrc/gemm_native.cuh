@@ -44,6 +44,8 @@ __device__ __forceinline__ void pin_acc(f32x4 &x) {
 // Workspace layout: qa[M][K] bytes (per 128-k tile: byte 32g + 16c + j holds k = 64c + 16g + j),
 // then qs[M][K/32] E8M0 bytes.
 __host__ __device__ inline size_t native_ws_bytes(unsigned m, unsigned k) { return (size_t)m * k + (size_t)m * (k / 32); }
+// the same rounded up to 256 B: where the fp32 slabs of a K split start inside a call's workspace
+__host__ __device__ inline size_t native_ws_aligned(unsigned m, unsigned k) { return (native_ws_bytes(m, k) + 255) & ~(size_t)255; }
 
 // One thread = 8 consecutive k of one row; the 4 threads of a quad share one 32-k block.
 template <class AT>
@@ -133,6 +135,10 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     const unsigned ntiles = p.n / kTileN;
     const unsigned nt0 = (blockIdx.x * WAVES + wave) * NTW;
     const unsigned m0 = blockIdx.y * Cfg::BM;
+    // K slice of this workgroup (gridDim.z > 1: see gemm_tiled.cuh)
+    const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
+    const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
+    const unsigned kt_begin = sp_begin * KS;
 
     f32x4 acc[MT][NTW];
 #pragma unroll
@@ -189,17 +195,17 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     const unsigned a_frag_hi = r * 8 + ((2 * g + 1) ^ swz);
     const unsigned a_scale_byte = r * 4 + g;                 // + mt*16*4, byte index into the scale array
 
-    dma_stage(0, 0);
+    dma_stage(kt_begin, 0); // (kt_begin is even)
     ScaleRec<kFmtMx, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
-        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, rel_tile(nt) * s_row_bytes);
+        srec[nt] = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff, rel_tile(nt) * s_row_bytes + sp_begin * 64 * kRecBytes);
     u32x4 wring[D][NTW];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            wring[i][nt] = buf_load16(w_rsrc, w_voff, rel_tile(nt) * w_row_bytes + i * kTileBytes, kAuxDefault);
+            wring[i][nt] = buf_load16(w_rsrc, w_voff, rel_tile(nt) * w_row_bytes + (kt_begin + i) * kTileBytes, kAuxDefault);
     __syncthreads();
 
     auto span_body = [&](const unsigned sp, auto last_c) {
@@ -291,9 +297,9 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
                 srec[nt] = srec_next[nt];
         }
     };
-    for (unsigned sp = 0; sp + 1 < nspans; ++sp)
+    for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
         span_body(sp, std::false_type{});
-    span_body(nspans - 1, std::true_type{});
+    span_body(sp_end - 1, std::true_type{});
 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -301,6 +307,18 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
         for (int nt = 0; nt < NTW; ++nt)
             pin_acc(acc[mt][nt]); // every MFMA executes with all 64 lanes, before the divergent stores
 
+    if (gridDim.z > 1) { // K split across workgroups: fp32 partial tile -> this slice's slab
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const unsigned m = m0 + mt * 16 + r;
+                const unsigned n = (nt0 + nt) * 16 + g * 4;
+                if (m < p.m && (unsigned)nt < valid_nt)
+                    *reinterpret_cast<f32x4 *>(p.workspace + ((size_t)blockIdx.z * p.m + m) * p.n + n) = acc[mt][nt];
+            }
+        return;
+    }
     const float gs = *p.gs;
     if (p.act) { // SiLU-mul: tiles (nt, nt + 1) are the gate / up halves of output tile (nt0 + nt) / 2
         if constexpr (NTW % 2 == 0) {

@@ -80,7 +80,6 @@ struct StreamCfg {
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmArgs p) {
     using AT = typename Cfg::AT;
-    using Frag = typename AT::frag;
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT;
     constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, AM = Cfg::AM, ABL = Cfg::ABL, PA = Cfg::PA;
     constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
@@ -186,45 +185,75 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             }
         };
         float bfp_up = 1.0f; // 2^sh of this lane's activation row for the span now in LDS
-        auto write_a_stage = [&]() {
+        // Block-floating-point spans are EXACT or not taken at all: a span whose rows all satisfy
+        // (smallest non-zero exponent) >= (largest exponent) - 31 converts to fp16 without losing a bit (a bf16 value
+        // has 8 significant bits; after the shift its last bit sits at >= 2^-24, fp16's subnormal step, and
+        // cvt_pkrtz is exact on representable values).  Any other span -- outliers, bf16 subnormals next to normal
+        // values, inf / NaN among finite data -- stays bf16 in LDS and runs through the bf16 pipeline
+        // (span_body<..., fallback>), so the kernel's result never depends on the activations' dynamic range.
+        // The switch is one-way per wave (first inexact span onwards), which keeps the control flow a chain of two loops.
+        bool bfp_fb = false; // wave-uniform: the span now in LDS (and every later one of this wave) is raw bf16
+        auto write_a_stage = [&](auto raw_c) {
+            constexpr bool kRaw = decltype(raw_c)::value; // already switched: no check, no conversion
             if constexpr (AM > 0 && (ABL & 1) == 0) {
-                if constexpr (AT::kBfp) {
+                if constexpr (AT::kBfp && !kRaw) {
                     constexpr int kPerRow = KS / 4;
-                    float up_row[AM];
+                    float up_row[AM], dn_row[AM];
+                    int inexact = 0;
 #pragma unroll
                     for (int rr = 0; rr < AM; ++rr) {
-                        // largest |bf16| bit pattern of the row's span: per lane, then across the wave
-                        unsigned mx = 0;
+                        // largest and smallest non-zero |bf16| bit pattern of the row's span, two halves at a time:
+                        // per lane, then across the wave.  (pattern - 1 wraps zero to 0xffff, so zeros never win the min.)
+                        u16x2 mx2 = u16x2{0, 0}, mn2 = u16x2{0xffff, 0xffff};
 #pragma unroll
                         for (int q = 0; q < kPerRow; ++q)
 #pragma unroll
                             for (int d = 0; d < 4; ++d) {
                                 const unsigned v = astage[rr * kPerRow + q][d] & 0x7fff7fffu;
-                                mx = max(mx, max(v & 0xffffu, v >> 16));
+                                const u16x2 pk = __builtin_bit_cast(u16x2, v);
+                                mx2 = __builtin_elementwise_max(mx2, pk);
+                                mn2 = __builtin_elementwise_min(mn2, (u16x2)(pk - u16x2{1, 1}));
                             }
+                        const unsigned short mx_l = mx2.x > mx2.y ? mx2.x : mx2.y, mn_l = mn2.x < mn2.y ? mn2.x : mn2.y;
+                        u16x2 c = u16x2{mx_l, (unsigned short)(0xffffu - mn_l)}; // one max-reduction serves both
 #pragma unroll
-                        for (int off = 32; off >= 1; off >>= 1)
-                            mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+                        for (int off = 32; off >= 1; off >>= 1) {
+                            const unsigned cu = __builtin_bit_cast(unsigned, c);
+                            const unsigned co = (unsigned)__shfl_xor((int)cu, off);
+                            c = __builtin_elementwise_max(c, __builtin_bit_cast(u16x2, co));
+                        }
+                        const unsigned mx = c.x, mn_m1 = 0xffffu - c.y; // mn_m1 = (smallest non-zero pattern) - 1
                         int sh = (int)(mx >> 7) - 141; // biased exponent - 127 - 14
                         sh = mx == 0 ? 0 : min(max(sh, -126), 126);
-                        const float dn = __builtin_bit_cast(float, (unsigned)(127 - sh) << 23);
+                        // exact iff every non-zero element's last bit survives: E - 134 - sh >= -24
+                        inexact |= (mn_m1 != 0xffffu && (int)((mn_m1 + 1u) >> 7) < sh + 110) ? 1 : 0;
+                        dn_row[rr] = __builtin_bit_cast(float, (unsigned)(127 - sh) << 23);
                         up_row[rr] = __builtin_bit_cast(float, (unsigned)(127 + sh) << 23);
-#pragma unroll
-                        for (int q = 0; q < kPerRow; ++q)
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const unsigned v = astage[rr * kPerRow + q][d];
-                                const unsigned lo_bits = v << 16, hi_bits = v & 0xffff0000u;
-                                const float lo = __builtin_bit_cast(float, lo_bits) * dn;
-                                const float hi = __builtin_bit_cast(float, hi_bits) * dn;
-                                const auto h2 = __builtin_amdgcn_cvt_pkrtz(lo, hi); // exact when in range
-                                astage[rr * kPerRow + q][d] = __builtin_bit_cast(unsigned, h2);
-                            }
                     }
-                    bfp_up = up_row[0];
+                    bfp_fb = __builtin_amdgcn_readfirstlane(inexact) != 0;
+                    if (!bfp_fb) {
 #pragma unroll
-                    for (int rr = 1; rr < AM; ++rr)
-                        bfp_up = (r == (unsigned)rr) ? up_row[rr] : bfp_up;
+                        for (int rr = 0; rr < AM; ++rr) {
+                            const float dn = dn_row[rr];
+#pragma unroll
+                            for (int q = 0; q < kPerRow; ++q)
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) {
+                                    const unsigned v = astage[rr * kPerRow + q][d];
+                                    const unsigned lo_bits = v << 16, hi_bits = v & 0xffff0000u;
+                                    const float lo = __builtin_bit_cast(float, lo_bits) * dn;
+                                    const float hi = __builtin_bit_cast(float, hi_bits) * dn;
+                                    const auto h2 = __builtin_amdgcn_cvt_pkrtz(lo, hi); // exact: checked above
+                                    astage[rr * kPerRow + q][d] = __builtin_bit_cast(unsigned, h2);
+                                }
+                        }
+                        bfp_up = up_row[0];
+#pragma unroll
+                        for (int rr = 1; rr < AM; ++rr)
+                            bfp_up = (r == (unsigned)rr) ? up_row[rr] : bfp_up;
+                    } else {
+                        bfp_up = 1.0f;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < kAStageLoads; ++i) {
@@ -290,7 +319,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
             }
         };
         if constexpr (AM > 0) {
-            write_a_stage(); // first stage's activations -> LDS
+            write_a_stage(std::false_type{}); // first stage's activations -> LDS
             load_first_frags();
             if constexpr (SL < KS)
                 issue_a_stage(sp_begin * (KS / SL) + 1, true);
@@ -303,8 +332,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
         // sched_barrier pins that order (hipcc otherwise sinks every refill to the end
         // of the span and copies the ring at the back edge, draining the pipeline).
         ScaleRec<FMT, KS> srec_next[NT];
-        auto span_body = [&](const unsigned sp, auto last_c) {
+        auto span_body = [&](const unsigned sp, auto last_c, auto fb_c) {
             constexpr bool kLast = decltype(last_c)::value;
+            // kFb: this span of a block-floating-point kernel holds raw bf16 activations (see write_a_stage)
+            constexpr bool kFb = decltype(fb_c)::value;
+            using ATX = std::conditional_t<kFb, Bf16, AT>;
+            using FragX = typename ATX::frag;
             const unsigned kt0 = sp * KS;
             if constexpr (!kLast) {
                 if constexpr (AM > 0 && SL == KS)
@@ -361,14 +394,14 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const unsigned w = wring[SLOT][nt][j];
-                        Frag wf;
+                        FragX wf;
                         if constexpr (ABL & 2) {
                             const unsigned sb = __builtin_bit_cast(unsigned, j < 2 ? s_lo : s_hi);
-                            wf = __builtin_bit_cast(Frag, u32x4{w, w ^ sb, w, sb});
+                            wf = __builtin_bit_cast(FragX, u32x4{w, w ^ sb, w, sb});
                         } else if constexpr (FMT == kFmtNv)
-                            wf = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
+                            wf = unpack_nv(ATX{}, w, j < 2 ? s_lo : s_hi);
                         else
-                            wf = unpack_mx(AT{}, w, s_lo);
+                            wf = unpack_mx(ATX{}, w, s_lo);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             f32x4 &a = acc[mt][nt][j % NACC];
@@ -376,13 +409,13 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                                 const u32x4 wb = __builtin_bit_cast(u32x4, wf), ab = afrag[mt][j];
                                 a += __builtin_bit_cast(f32x4, wb ^ ab);
                             } else if constexpr (AT::kSplit && AM > 0) {
-                                a = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), a);
-                                a = mfma16(wf, __builtin_bit_cast(Frag, afrag_lo[j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(FragX, afrag[mt][j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(FragX, afrag_lo[j]), a);
                             } else if constexpr (AT::kSplit) {
-                                a = mfma16(wf, __builtin_bit_cast(Frag, asplit_hi[mt][j]), a);
-                                a = mfma16(wf, __builtin_bit_cast(Frag, asplit_lo[mt][j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(FragX, asplit_hi[mt][j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(FragX, asplit_lo[mt][j]), a);
                             } else
-                                a = mfma16(wf, __builtin_bit_cast(Frag, afrag[mt][j]), a);
+                                a = mfma16(wf, __builtin_bit_cast(FragX, afrag[mt][j]), a);
                         }
                     }
                 }
@@ -418,7 +451,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     // stage boundary inside (or at the end of) the span: every fragment of the old
                     // stage has been read (LDS is in order within a wave), so the slice takes the
                     // stage held in VGPRs, and the one after it is requested
-                    write_a_stage();
+                    write_a_stage(fb_c);
                     load_first_frags();
                     const unsigned st_next = (kt + 1) / SL + 1;
                     if constexpr (!kLast || (T + 1 + SL < KS))
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                 // every fragment of this span has been read (LDS is in order within a
                 // wave): the slice can take the next span's activations
                 if constexpr (AM > 0 && SL == KS) {
-                    write_a_stage();
+                    write_a_stage(fb_c);
                     load_first_frags();
                 }
 #pragma unroll
@@ -448,9 +481,24 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmAr
                     srec[nt] = srec_next[nt];
             }
         };
-        for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
-            span_body(sp, std::false_type{});
-        span_body(sp_end - 1, std::true_type{});
+        if constexpr (AT::kBfp) {
+            // exact block-floating-point spans first; from the first span that fails the range check (its flag is set
+            // by the write_a_stage that put it in LDS: the prologue's, or the previous span's) the bf16 pipeline
+            unsigned sp = sp_begin;
+            for (; sp + 1 < sp_end && !bfp_fb; ++sp)
+                span_body(sp, std::false_type{}, std::false_type{});
+            if (!bfp_fb) {
+                span_body(sp_end - 1, std::true_type{}, std::false_type{});
+            } else {
+                for (; sp + 1 < sp_end; ++sp)
+                    span_body(sp, std::false_type{}, std::true_type{});
+                span_body(sp_end - 1, std::true_type{}, std::true_type{});
+            }
+        } else {
+            for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+                span_body(sp, std::false_type{}, std::false_type{});
+            span_body(sp_end - 1, std::true_type{}, std::false_type{});
+        }
     }
 
     // --- cross-wave K reduction through LDS, then the epilogue -----------------

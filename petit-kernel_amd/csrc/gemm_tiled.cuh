@@ -27,6 +27,9 @@ namespace petit_amd {
 //   NTW  n-tiles (of 16) per wave                          (BN = 16*NTW*WAVES)
 //   WAVES waves per workgroup (along N)
 //   D    W ring depth in k-tiles
+// gridDim.z > 1 splits K across workgroups (contiguous spans per slice, spans_per_wave of them): every slice writes its
+// fp32 partial tile into its slab of p.workspace and splitk_reduce_kernel sums the slabs in a fixed order (deterministic;
+// the reference has no K split at all, gemm_fp4_fp16_grid.cuh:554-555, and leaves half the chip idle at M = 512, N = 8192).
 template <class AT_, int FMT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct TiledCfg {
     using AT = AT_;
     static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NTW = NTW_, WAVES = WAVES_, D = D_;
@@ -72,6 +75,10 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
     const unsigned ntiles = p.n / kTileN;
     const unsigned nt0 = (blockIdx.x * WAVES + wave) * NTW;
     const unsigned m0 = blockIdx.y * Cfg::BM;
+    // K slice of this workgroup (whole spans; the host guarantees every slice is non-empty)
+    const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
+    const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
+    const unsigned kt_begin = sp_begin * KS;
 
     f32x4 acc[MT][NTW];
 #pragma unroll
@@ -137,22 +144,22 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
     // --- prologue
     u32x4 astage[Cfg::kDma ? 1 : UPT];
     if constexpr (Cfg::kDma) {
-        dma_a_tile(smem, 0u);
+        dma_a_tile(smem, kt_begin); // (kt_begin is even: KS is, so the first tile lands in buffer 0)
     } else {
 #pragma unroll
         for (int i = 0; i < UPT; ++i)
-            astage[i] = buf_load16(a_rsrc, a_g_voff[i], 0u, kAuxDefault);
+            astage[i] = buf_load16(a_rsrc, a_g_voff[i], kt_begin * 256, kAuxDefault);
     }
     ScaleRec<FMT, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
-        srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], 0u);
+        srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], sp_begin * 64 * kRecBytes);
     u32x4 wring[D][NTW];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
-            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], i * kTileBytes, kAuxDefault);
+            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxDefault);
     auto store_a_tile = [&](u32x4 *dst) {
         if constexpr (Cfg::kDma)
             return; // already on its way into LDS
@@ -257,10 +264,22 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
                 srec[nt] = srec_next[nt];
         }
     };
-    for (unsigned sp = 0; sp + 1 < nspans; ++sp)
+    for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
         span_body(sp, std::false_type{});
-    span_body(nspans - 1, std::true_type{});
+    span_body(sp_end - 1, std::true_type{});
 
+    if (gridDim.z > 1) { // K split across workgroups: fp32 partial tile -> this slice's slab
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const unsigned m = m0 + mt * 16 + r;
+                const unsigned n = (nt0 + nt) * 16 + g * 4;
+                if (m < p.m && (unsigned)nt < valid_nt)
+                    *reinterpret_cast<f32x4 *>(p.workspace + ((size_t)blockIdx.z * p.m + m) * p.n + n) = acc[mt][nt];
+            }
+        return;
+    }
     // --- epilogue: x global scale, one RNE rounding, 8-byte stores
     const float gs = *p.gs;
     if (p.act) { // SiLU-mul: tiles (nt, nt + 1) are the gate / up halves of output tile (nt0 + nt) / 2

@@ -80,6 +80,8 @@ void load_override() {
         unsigned long long sol = 0;
         if (sscanf(line, "%d %d %u %u %u %u %llx", &e.a_type, &e.b_type, &e.n, &e.k, &e.m_lo, &e.m_hi, &sol) == 7) {
             e.solution = sol;
+            if (((sol >> 48) & 0xf) == 9)
+                continue; // a native-FP4 kernel is never a default (own accuracy class): the row is ignored
             g_override.push_back(e);
         }
     }

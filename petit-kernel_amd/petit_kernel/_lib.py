@@ -43,6 +43,11 @@ _SIGNATURES = {
                                     [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p]),
     "petit_gemm_mxfp4_fp16_grid_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
                                       [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p]),
+    "petit_gemm_fp4_fp16_grid_ws": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
+                                    [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "petit_gemm_mxfp4_fp16_grid_ws": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
+                                      [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "petit_gemm_workspace_bytes": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64]),
     "petit_gemm_fp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
                                  [C.POINTER(SolutionHints), C.c_uint64, C.c_void_p]),
     "petit_gemm_mxfp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +

@@ -144,6 +144,21 @@ def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torc
 
 _ACTIVATIONS = {None: 0, "none": 0, "silu_mul": 1}   # PETIT_ACTIVATION_* (include/petit_amd.h)
 
+_ws_need_cache = {}
+
+
+def _workspace_need(a_type: int, b_type: int, m: int, n: int, k: int, sid: int) -> int:
+    """petit_gemm_workspace_bytes, memoised per problem (a pure function of its arguments)."""
+    key = (a_type, b_type, m, n, k, sid)
+    need = _ws_need_cache.get(key)
+    if need is None:
+        hints = _CHints(a_type, b_type, a_type, 0)
+        need = int(_lib.lib.petit_gemm_workspace_bytes(C.byref(hints), m, n, k, C.c_uint64(sid)))
+        if len(_ws_need_cache) > 4096:
+            _ws_need_cache.clear()
+        _ws_need_cache[key] = need
+    return need
+
 
 def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
     if A.dtype != torch.bfloat16 and A.dtype != torch.float16:
@@ -166,21 +181,26 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
     sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
-    if bias is None and not act:
-        fn = _lib.lib.petit_gemm_fp4_fp16_grid if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
-        with torch.cuda.device(A.device):
-            err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
-                     C.byref(hints), C.c_uint64(sid), _stream(A))
-    else:
+    epi = None
+    if bias is not None or act:
         # fused epilogue (include/petit_amd.h, petit_epilogue): c = round16(act(acc * gs + bias[n]))
         if bias is not None:
             _check(bias.is_cuda and bias.device == A.device and bias.dtype == A.dtype and bias.is_contiguous() and
                    bias.numel() == size_n, "bias must be a contiguous [size_n] tensor of A's dtype on A's device")
         epi = _lib.Epilogue(bias.data_ptr() if bias is not None else None, act, 0)
-        fn = _lib.lib.petit_gemm_fp4_fp16_grid_ex if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid_ex
-        with torch.cuda.device(A.device):
-            err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
-                     C.byref(hints), C.c_uint64(sid), C.byref(epi), _stream(A))
+    # Scratch for kernels that need it (cross-workgroup K split, native-FP4 path): per call, from torch's
+    # stream-ordered caching allocator -- safe with several streams and under graph capture.  A workspace
+    # registered with set_workspace() is honoured instead (round-1 behaviour) when one is set for this device.
+    ws, ws_bytes = None, 0
+    if A.device.index not in _workspace_keepalive:
+        ws_bytes = _workspace_need(a_type, b_type, size_m, size_n, size_k, sid)
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+    fn = _lib.lib.petit_gemm_fp4_fp16_grid_ws if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid_ws
+    with torch.cuda.device(A.device):
+        err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
+                 C.byref(hints), C.c_uint64(sid), C.byref(epi) if epi is not None else None,
+                 _ptr(ws) if ws is not None else None, C.c_uint64(ws_bytes), _stream(A))
     if err == _lib.PETIT_ERROR_PROBLEM_SHAPE:
         raise RuntimeError(f"Incompatible problem shape (m={size_m}, n={size_n}, k={size_k})")
     if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
@@ -250,12 +270,21 @@ def native_workspace_bytes(size_m: int, size_k: int) -> int:
     return int(_lib.lib.petit_native_workspace_bytes(size_m, size_k))
 
 
+def workspace_bytes(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, solution_id: int = -1) -> int:
+    """Scratch bytes the call would use (split-K slabs, native-FP4 activations); mul_*_a16 allocates them itself."""
+    sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
+    ch = _c_hints(hints)
+    return int(_lib.lib.petit_gemm_workspace_bytes(C.byref(ch), size_m, size_n, size_k, C.c_uint64(sid)))
+
+
 _workspace_keepalive = {}
 
 
 def set_workspace(buf) -> None:
     """Register (or with None, unregister) a device scratch tensor for kernels that need one
-    (split-K slabs, quantised activations of the native path).  The tensor is kept alive here."""
+    (split-K slabs, quantised activations of the native path).  The tensor is kept alive here.
+    Optional: without a registered workspace mul_*_a16 allocates the scratch per call.  A registered
+    workspace serves ONE stream (include/petit_amd.h "Scratch memory")."""
     if buf is None:
         with torch.cuda.device(torch.cuda.current_device()):
             _lib.lib.petit_set_workspace(None, 0)

@@ -85,8 +85,10 @@ def mx_case(ref, m, n, k, seed, dtype):
     dq = (dq.view(n, -1, 32) * sc.unsqueeze(-1)).view(n, -1)
     # reference MX test: ((a.float() @ b.T.float()) * gs).to(dtype)  (:87)
     c_ref = ((a.float() @ dq.t().float()) * gs.item()).to(a.dtype)
+    # and the imported _gemm_ref itself on the gs-scaled weights, the way the reference's NV test calls it (:49-50)
+    c_ref_gemm = ref._gemm_ref(a, dq * gs.item())
     return dict(a=bits16(a), q=q.numpy(), s=s.numpy(), gs=gs.numpy(),
-                b_dq=dq.numpy(), c_ref=bits16(c_ref),
+                b_dq=dq.numpy(), c_ref=bits16(c_ref), c_ref_gemm=bits16(c_ref_gemm),
                 a_is_bf16=np.array(dtype == torch.bfloat16))
 
 

@@ -417,6 +417,116 @@ def test_concurrent_host_threads_and_streams(pk):
     assert not errors, errors
 
 
+def test_two_streams_concurrent_split_k(pk):
+    """Two GEMMs that need scratch memory (cross-workgroup K split: stream kernel, tiled kernel) enqueued concurrently on
+    two streams of one device from two host threads: the Python layer hands each CALL its own workspace (per-call
+    scratch through petit_gemm_*_ws), so nothing can overwrite another call's slabs (round-1 ADVICE: one global
+    workspace per device was a silent race)."""
+    import threading
+    specs = [("nv", True, 24, 512, 8192, 0), ("nv", True, 160, 256, 8192, 8), ("mx", True, 48, 256, 4096, 0), ("mx", True, 130, 128, 4096, 8)]
+    probs = []
+    for i, (kind, is_bf16, m, n, k, want_kind) in enumerate(specs):
+        a, q, s, gs = random_problem(kind, m, n, k, 7000 + i, is_bf16)
+        h = pk.PetitSolutionHints()
+        h.a_type = h.c_type = torch.bfloat16
+        h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+        sid = next(x for x in pk.ops.get_fp4_solutions(h, m, n, k) if (x >> 48) & 0xF == want_kind)
+        sid = (sid & ~(0xF << 60)) | (2 << 60)
+        assert pk.ops.workspace_bytes(h, m, n, k, sid) == 2 * m * n * 4
+        probs.append((kind, is_bf16, m, n, k, sid, a, q, s, gs, oracle_ref(kind, a, is_bf16, q, s, gs),
+                      oracle_sum_abs(kind, a, is_bf16, q, s, gs)))
+    errors = []
+
+    def worker(p):
+        try:
+            kind, is_bf16, m, n, k, sid, a, q, s, gs, ref, sum_abs = p
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(25):
+                    check_gemm(run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid), ref, is_bf16, sum_abs)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(p,)) for p in probs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_registered_workspace_serves_one_stream(pk):
+    """The legacy per-device workspace (petit_set_workspace) binds to the first stream that uses it: an explicit
+    scratch-needing id from another stream is refused loudly instead of racing; AUTO falls back to a kernel without
+    scratch; re-registering rebinds."""
+    from petit_kernel import _lib
+    import ctypes as C
+    m, n, k = 24, 256, 4096
+    a, q, s, gs = random_problem("nv", m, n, k, 8100, True)
+    ref = oracle_ref("nv", a, True, q, s, gs)
+    ad = from_bits(a, torch.bfloat16).to(DEV)
+    b = pk.repack_nvfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+    sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+    c = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
+    hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16
+    h.b_type = pk.DataType.float4_e2m1
+    sid = next(x for x in pk.ops.get_fp4_solutions(h, m, n, k) if (x >> 48) & 0xF == 0)
+    sid = (sid & ~(0xF << 60)) | (2 << 60)
+    ws = torch.empty(2 * m * n, dtype=torch.float32, device=DEV)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def call(stream, solution):
+        rc = _lib.lib.petit_gemm_fp4_fp16_grid(c.data_ptr(), ad.data_ptr(), b.data_ptr(), sp.data_ptr(), gsd.data_ptr(), m, n, k,
+                                               C.byref(hints), C.c_uint64(solution), C.c_void_p(stream.cuda_stream))
+        stream.synchronize()
+        return rc
+
+    torch.cuda.synchronize()
+    assert call(s1, sid) == _lib.PETIT_ERROR_KERNEL_SHAPE           # nothing registered, no per-call scratch
+    pk.ops.set_workspace(ws)
+    try:
+        assert call(s1, sid) == 0
+        check_gemm(bits(c), ref, True)
+        assert call(s2, sid) == _lib.PETIT_ERROR_BAD_ARGUMENT       # bound to s1: refused, not raced
+        assert call(s1, sid) == 0
+        c.zero_()
+        assert call(s2, _lib.PETIT_SOLUTION_AUTO) == 0              # AUTO never needs the registered scratch
+        check_gemm(bits(c), ref, True)
+        pk.ops.set_workspace(ws)                                    # re-register: binds again, to whoever comes first
+        assert call(s2, sid) == 0
+        check_gemm(bits(c), ref, True)
+        assert call(s1, sid) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    finally:
+        pk.ops.set_workspace(None)
+
+
+@pytest.mark.parametrize("is_bf16", [True, False])
+def test_nv_typed_solution_ids_work_with_mxfp4(pk, is_bf16):
+    """get_fp4_solutions(m, n, k, a_type, c_type) hard-codes b_type = FP4_E2M1 (petit_kernel/__init__.py:63-66), so
+    its ids carry the NVFP4 element nibble; the reference's MX entry point rewrites the nibble and dispatches
+    (gemm_fp4_fp16_grid.cc:79-95).  Same here: every such id (block-floating-point ones map to their plain staged
+    twins) must run mul_mxfp4_a16, or be refused as a kernel-shape error -- never as garbage."""
+    m, n, k = 4, 128, 2048
+    a, q, s, gs = random_problem("mx", m, n, k, 8200, is_bf16)
+    ref = oracle_ref("mx", a, is_bf16, q, s, gs)
+    sum_abs = oracle_sum_abs("mx", a, is_bf16, q, s, gs)
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    ids = pk.get_fp4_solutions(m, n, k, dtype, dtype)
+    assert ids and all((sid >> 28) & 0xF == 1 for sid in ids)
+    ran = 0
+    for sid in ids:
+        try:
+            c = run_case(pk, "mx", a, is_bf16, q, s, gs, m, n, k, sid)
+        except RuntimeError as exc:
+            assert "No kernel implementation" in str(exc)
+            continue
+        check_gemm(c, ref, is_bf16, sum_abs)
+        ran += 1
+    assert ran >= len(ids) // 2
+
+
 def test_offline_repack_matches_device(pk):
     """petit_kernel.offline (CPU, checkpoint-side tooling) == the device repack, bit for bit, and the GEMM
     accepts the CPU-packed tensors."""
@@ -519,6 +629,111 @@ def test_fused_silu_mul_epilogue(pk, kind, is_bf16, with_bias, m, n, k):
     assert served >= 2
 
 
+# --- adversarial activations: the kernels must not depend on the activations' dynamic range ---------------
+
+SPAN = 1024   # k per span at KS = 8: the block-floating-point unit of the Bf16Bfp kernels (csrc/gemm_stream.cuh)
+
+
+def adversarial_activations(m, k, q, is_bf16, seed, profile):
+    """Rows x spans of hostile data.  Span types cycle so that every wave of every K split meets several
+    (profile 0: types 0 2 3 4 6, whose contributions to the result are all O(1) so that what an inexact conversion of a
+    type-2 span loses is visible at the 1 % bound; profile 1: types 1 and 5 as well, results dominated by huge terms):
+      0 N(0,1)                         1 N(0,1) * 2^U[-17,17]: 35 binades inside one span
+      2 O(1) values + one huge outlier at a column whose weights are ALL ZERO (the small values carry the
+        result, an fp16 block-floating-point span would truncate them)     3 all zero (incl. -0.0)
+      4 subnormals of the activation type next to one normal value          5 tiny values + an outlier with weight
+      6 N(0,1) (exact BFP span AFTER hostile ones: the switch is one-way per wave)
+    Returns (a_bits, q) -- q is edited in place so that type-2 outlier columns hold weight code 0 / 8 (+-0)."""
+    rng = np.random.default_rng(seed)
+    big = 2.0 ** 36 if is_bf16 else 32768.0
+    a = np.zeros((m, k), dtype=np.float32)
+    raw_sub = np.zeros((m, k), dtype=bool)
+    sub_bits = np.zeros((m, k), dtype=np.uint16)
+    for row in range(m):
+        for sp in range(k // SPAN):
+            sl = slice(sp * SPAN, (sp + 1) * SPAN)
+            t = ((0, 2, 3, 4, 6, 2, 0, 2) if profile == 0 else (1, 5, 0, 2, 1, 4, 6, 5))[(sp + 3 * row) % 8]
+            x = rng.standard_normal(SPAN).astype(np.float32)
+            if t == 1:
+                x = x * np.exp2(rng.integers(-17, 18, SPAN) if is_bf16 else rng.integers(-10, 4, SPAN)).astype(np.float32)
+            elif t == 2:
+                col = int(rng.integers(0, SPAN))
+                x[col] = big * (1 if rng.random() < 0.5 else -1)
+                q[:, (sp * SPAN + col) // 2] &= (0x80 if col % 2 else 0x08) | (0x0F if col % 2 else 0xF0)  # magnitude bits -> 0
+            elif t == 3:
+                x[:] = 0.0
+                x[::3] = -0.0
+            elif t == 4:
+                x[:] = 0.0
+                raw_sub[row, sl] = True
+                sub_bits[row, sl] = rng.integers(1, 0x80 if is_bf16 else 0x400, SPAN).astype(np.uint16) | \
+                    (rng.integers(0, 2, SPAN).astype(np.uint16) << 15)
+                raw_sub[row, sp * SPAN + 5] = False
+                x[5] = 1.5
+            elif t == 5:
+                x = x * np.float32(1e-6)
+                x[int(rng.integers(0, SPAN))] = big
+            a[row, sl] = x
+    a_bits = O.f32_to_bf16_bits(a) if is_bf16 else a.astype(np.float16).view(np.uint16)
+    a_bits = np.where(raw_sub, sub_bits, a_bits).astype(np.uint16)
+    return a_bits, q
+
+
+@pytest.mark.parametrize("profile", [0, 1])
+@pytest.mark.parametrize("m", [1, 2, 4, 7])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
+def test_adversarial_activations_every_solution(pk, kind, is_bf16, m, profile):
+    """Outliers, 35-binade spans, subnormals, zero spans: every enumerated kernel (the block-floating-point
+    Bf16Bfp ones in particular: they must detect the spans they cannot convert exactly and run those through the
+    bf16 pipeline) against the oracle at the usual 1e-2 bound.  K = 16 spans, so waves own several spans each."""
+    n, k = 64, 16 * SPAN
+    _, q, s, gs = random_problem(kind, m, n, k, 31337 + m, is_bf16, mx_band=(124, 130))
+    a, q = adversarial_activations(m, k, q, is_bf16, 4000 + m, profile)
+    ref = oracle_ref(kind, a, is_bf16, q, s, gs)
+    sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
+    assert np.isfinite(ref).all()
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+    sols = pk.ops.get_fp4_solutions(h, m, n, k)
+    if kind == "nv" and is_bf16 and m <= 4:
+        assert any((sid >> 48) & 0xF in (5, 6, 7) for sid in sols), "the block-floating-point kernels must be in the list"
+    for sid in [-1] + list(sols):
+        c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid)
+        try:
+            check_gemm(c, ref, is_bf16, sum_abs)
+        except AssertionError as exc:
+            raise AssertionError(f"solution {sid:#x}: {exc}") from None
+
+
+@pytest.mark.parametrize("m", [1, 4])
+def test_nonfinite_activations(pk, m):
+    """+-inf / NaN in the activations propagate like IEEE arithmetic does in the oracle: NaN where the oracle has NaN
+    (inf x zero weight, NaN x anything), the same signed infinity elsewhere, finite outputs untouched -- every
+    bf16 x NVFP4 kernel, BFP included (an inf makes the span's range check fail or scales to inf, both correct)."""
+    n, k = 64, 4 * SPAN
+    a, q, s, gs = random_problem("nv", m, n, k, 777 + m, True)
+    a = a.copy()
+    a[0, 100] = 0x7F80                      # +inf in span 0
+    a[m - 1, 2 * SPAN + 7] = 0xFF80         # -inf in span 2
+    if m > 1:
+        a[1, 3 * SPAN + 9] = 0x7FC0         # NaN in row 1
+    q[::2, 50] &= 0x80                       # column 100 = low nibble of byte 50: zero weight for even n -> inf * 0 = NaN there
+    with np.errstate(all="ignore"):
+        ref = oracle_ref("nv", a, True, q, s, gs)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16
+    h.b_type = pk.DataType.float4_e2m1
+    for sid in [-1] + list(pk.ops.get_fp4_solutions(h, m, n, k)):
+        got = to_f32(run_case(pk, "nv", a, True, q, s, gs, m, n, k, sid), True)
+        assert np.array_equal(np.isnan(got), np.isnan(ref)), f"{sid:#x}"
+        inf = np.isinf(ref)
+        assert np.array_equal(np.isinf(got), inf) and np.array_equal(np.sign(got[inf]), np.sign(ref[inf])), f"{sid:#x}"
+        fin = np.isfinite(ref)
+        if fin.any():
+            assert (np.abs(got - ref)[fin] <= np.maximum(1e-2, 1e-2 * np.abs(ref[fin]))).all(), f"{sid:#x}"
+
+
 # --- BASELINE.json full sizes: oracle on the whole problem + size-independent properties --
 
 @pytest.mark.parametrize("m", [1, 16])
@@ -568,6 +783,155 @@ def test_llama70b_shapes_properties(pk, n, k):
     dq = O.dequant_nvfp4(q[rows], s[rows])
     _, cf = O.gemm_ref(bits(a8), True, dq, 1.0)
     check_gemm(bits(c8[:, torch.from_numpy(rows).to(DEV)]), cf, True)
+
+
+LLAMA70B = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "down": (8192, 28672)}
+
+
+class FullSizeProblem:
+    """One Llama-3-70B linear at its real size on the device (BASELINE.json configs[2..4]); weights are drawn and
+    repacked once per (kind, shape) and reused for every M / dtype / solution of the test."""
+
+    def __init__(self, pk, kind, n, k, seed):
+        self.pk, self.kind, self.n, self.k = pk, kind, n, k
+        _, self.q, self.s, _ = random_problem(kind, 1, n, k, seed, True)
+        qd = torch.from_numpy(self.q).to(DEV)
+        if kind == "nv":
+            self.b = pk.repack_nvfp4(qd.view(torch.int32), n, k)
+            self.sp = pk.process_nvfp4_scales(torch.from_numpy(self.s).to(DEV).view(torch.float8_e4m3fn), n, k)
+            self.mul = pk.mul_nvfp4_a16
+        else:
+            self.b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
+            self.sp = pk.process_mxfp4_scales(torch.from_numpy(self.s).to(DEV), n, k)
+            self.mul = pk.mul_mxfp4_a16
+        del qd
+        self.gs = 0.75
+        self.gsd = torch.tensor([self.gs], dtype=torch.float32, device=DEV)
+        rng = np.random.default_rng(seed + 1)
+        # 64 sampled output columns, always including the first and last n-tile (largest buffer offsets)
+        self.rows = np.unique(np.concatenate([rng.integers(0, n, 60), [0, 15, n - 16, n - 1]]))
+        dq = O.dequant_nvfp4(self.q[self.rows], self.s[self.rows]) if kind == "nv" else O.dequant_mxfp4(self.q[self.rows], self.s[self.rows])
+        self.dq = dq
+
+    def hints(self, is_bf16):
+        h = self.pk.PetitSolutionHints()
+        h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+        h.b_type = self.pk.DataType.float4_e2m1 if self.kind == "nv" else self.pk.DataType.mxfloat4_e2m1
+        return h
+
+    def activations(self, m, is_bf16, seed):
+        a = np.random.default_rng(seed).standard_normal((m, self.k), dtype=np.float32)
+        return O.f32_to_bf16_bits(a) if is_bf16 else a.astype(np.float16).view(np.uint16)
+
+    def run(self, a_bits, is_bf16, sid=-1):
+        dtype = torch.bfloat16 if is_bf16 else torch.float16
+        m = a_bits.shape[0]
+        c = self.mul(from_bits(a_bits, dtype).to(DEV), self.b, self.sp, self.gsd, m, self.n, self.k, sid)
+        torch.cuda.synchronize()
+        return c
+
+    def check_sampled(self, c, a_bits, is_bf16, tag=""):
+        _, cf = O.gemm_ref(a_bits, is_bf16, self.dq, self.gs)
+        sum_abs = None
+        if self.kind == "mx":
+            sum_abs = (np.abs(to_f32(a_bits, is_bf16)) @ np.abs(self.dq).T) * self.gs
+        try:
+            check_gemm(bits(c[:, torch.from_numpy(self.rows).to(DEV)]), cf, is_bf16, sum_abs)
+        except AssertionError as exc:
+            raise AssertionError(f"{tag}: {exc}") from None
+
+    def check_properties(self, m, is_bf16, sid=-1):
+        """zero in -> zero out; one-hot rows read back exact dequantised weight columns (every output column)."""
+        dtype = torch.bfloat16 if is_bf16 else torch.float16
+        k, n = self.k, self.n
+        zero = torch.zeros((m, k), dtype=dtype, device=DEV)
+        assert torch.count_nonzero(self.mul(zero, self.b, self.sp, torch.ones(1, device=DEV), m, n, k, sid)) == 0
+        cols = [0, 31, 32, 127, 128, 1023, 1024, k // 2 + 17, k - 1][:m]
+        onehot = torch.zeros((m, k), dtype=dtype, device=DEV)
+        for i, c_ in enumerate(cols):
+            onehot[i, c_] = 1.0
+        got = self.mul(onehot, self.b, self.sp, torch.ones(1, device=DEV), m, n, k, sid).float().cpu().numpy()
+        for i, c_ in enumerate(cols):
+            nib = (self.q[:, c_ // 2] >> (4 * (c_ % 2))) & 15
+            sc = O.e4m3_to_f32(self.s[:, c_ // 16]) if self.kind == "nv" else O.e8m0_to_f32(self.s[:, c_ // 32])
+            assert np.array_equal(got[i], O.FP4_VALUES[nib] * sc), f"one-hot column {c_}"
+
+
+def test_gate_up_full_size_bf16_nvfp4(pk):
+    """configs[2], the widest shape: gate_up 57344 x 8192 at M in {1, 4, 8, 16, 32} through solution_id = -1 (M = 9..32
+    takes the 16x256 / 32x256 tiled kernels via the arch table: the largest buffer offsets in the library) and through
+    one explicit kernel of each kind that serves that M."""
+    n, k = LLAMA70B["gate_up"]
+    P = FullSizeProblem(pk, "nv", n, k, 57344)
+    for m in (1, 4, 8, 16, 32):
+        a = P.activations(m, True, 100 + m)
+        P.check_properties(m, True)
+        P.check_sampled(P.run(a, True), a, True, f"auto M={m}")
+        sols = pk.ops.get_fp4_solutions(P.hints(True), m, n, k)
+        by_kind = {}
+        for sid in sols:
+            by_kind.setdefault((sid >> 48) & 0xF, sid)
+        for sid in by_kind.values():
+            P.check_sampled(P.run(a, True, sid), a, True, f"M={m} sid={sid:#x}")
+
+
+@pytest.mark.parametrize("shape", ["qkv", "o", "gate_up", "down"])
+def test_llama70b_fp16_mxfp4_full_size(pk, shape):
+    """configs[3]: MXFP4 weights (e8m0 block scales) x fp16 activations on every Llama-3-70B linear, M in {1, 16}:
+    default pick + one explicit kernel per kind, properties + sampled columns vs the oracle."""
+    n, k = LLAMA70B[shape]
+    P = FullSizeProblem(pk, "mx", n, k, n + k)
+    for m in (1, 16):
+        a = P.activations(m, False, 200 + m)
+        P.check_properties(m, False)
+        P.check_sampled(P.run(a, False), a, False, f"auto M={m}")
+        by_kind = {}
+        for sid in pk.ops.get_fp4_solutions(P.hints(False), m, n, k):
+            by_kind.setdefault((sid >> 48) & 0xF, sid)
+        for sid in by_kind.values():
+            P.check_sampled(P.run(a, False, sid), a, False, f"M={m} sid={sid:#x}")
+
+
+@pytest.mark.parametrize("shape", ["o", "qkv"])
+@pytest.mark.parametrize("kind", ["nv", "mx"])
+def test_m512_full_size_tiled_and_native(pk, kind, shape):
+    """configs[4]: M = 512 on 8192^2 and qkv -- the default pick, EVERY tiled kernel (split-K variants included
+    when a workspace is registered) and, for MXFP4, every native-FP4 kernel at its own tolerance."""
+    n, k = LLAMA70B[shape]
+    m = 512
+    P = FullSizeProblem(pk, kind, n, k, 512 + n)
+    a = P.activations(m, True, 300)
+    P.check_sampled(P.run(a, True), a, True, "auto")
+    ws = torch.empty(max(pk.ops.native_workspace_bytes(m, k), 4 * 4 * m * n), dtype=torch.uint8, device=DEV)
+    pk.ops.set_workspace(ws)
+    pk.ops.enable_native_fp4(True)
+    try:
+        sols = pk.ops.get_fp4_solutions(P.hints(True), m, n, k)
+        tiled = [sid for sid in sols if (sid >> 48) & 0xF == 8]
+        native = [sid for sid in sols if (sid >> 32) & 7 == 2]
+        assert tiled
+        for sid in tiled:
+            P.check_sampled(P.run(a, True, sid), a, True, f"tiled {sid:#x}")
+            for splitk in (2, 4):
+                sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                P.check_sampled(P.run(a, True, sk), a, True, f"tiled split-K {sk:#x}")
+        if kind == "mx":
+            assert native
+            a_q = O.f32_to_bf16_bits(quantize_act_mxfp8(to_f32(a, True)))
+            _, exact = O.gemm_ref(a_q, True, P.dq, P.gs)
+            sum_abs = (np.abs(to_f32(a, True)) @ np.abs(P.dq).T) * P.gs
+            _, full = O.gemm_ref(a, True, P.dq, P.gs)
+            cols = torch.from_numpy(P.rows).to(DEV)
+            for sid in native:
+                for splitk in (1, 2):
+                    sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                    c = to_f32(bits(P.run(a, True, sk)[:, cols]), True).astype(np.float64)
+                    err = np.abs(c - exact)
+                    assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)).all(), f"native {sk:#x}"
+                    assert (np.abs(c - full) <= 2e-2 * sum_abs + 1e-2).all(), f"native {sk:#x}"
+    finally:
+        pk.ops.set_workspace(None)
+        pk.ops.enable_native_fp4(False)
 
 
 # --- the native-FP4 path (opt-in): exact semantics + its own stated tolerance ---------------------

@@ -277,6 +277,56 @@ def test_arch_table_rows_and_tune_file_override(tmp_path):
     assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": ""}, at, bt, lo, n, k) == sol
 
 
+def test_tune_file_native_row_is_ignored_for_auto(tmp_path):
+    """PETIT_SOLUTION_AUTO never runs a native-FP4 kernel (different accuracy class), even when a tune file produced
+    with `tools/tune.py --native` names one: the row is skipped and the exact-kernel choice stands."""
+    from petit_kernel import _lib
+    at, bt, m, n, k = _lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, 512, 8192, 8192
+    hints = _lib.SolutionHints(at, bt, at, 0)
+    want = _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k)
+    assert want and (want >> 48) & 0xF != 9
+    _lib.lib.petit_enable_native_fp4(1)
+    try:
+        cnt = C.c_uint(0)
+        assert _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, None, C.byref(cnt)) == 0
+        ids = (C.c_uint64 * cnt.value)()
+        assert _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, ids, C.byref(cnt)) == 0
+    finally:
+        _lib.lib.petit_enable_native_fp4(0)
+    native = next(i for i in ids if (i >> 48) & 0xF == 9)
+    tune = tmp_path / "tune.txt"
+    tune.write_text(f"{at} {bt} {n} {k} {m} {m} {native:x}\n")
+    got = _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune), "PETIT_AMD_NATIVE_FP4": "1"}, at, bt, m, n, k)
+    assert got == want, (hex(got), hex(want))
+
+
+def test_workspace_bytes_query():
+    """petit_gemm_workspace_bytes: 0 for plain kernels, splitk * m * n * 4 for a cross-workgroup K split (stream and
+    tiled kernels), quantised activations (+ slabs) for the native kernels."""
+    from petit_kernel import _lib
+    at, bt, m, n, k = _lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, 512, 8192, 8192
+    hints = _lib.SolutionHints(at, bt, at, 0)
+    _lib.lib.petit_enable_native_fp4(1)
+    try:
+        cnt = C.c_uint(0)
+        _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, None, C.byref(cnt))
+        ids = (C.c_uint64 * cnt.value)()
+        _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, ids, C.byref(cnt))
+    finally:
+        _lib.lib.petit_enable_native_fp4(0)
+    need = lambda sid: _lib.lib.petit_gemm_workspace_bytes(C.byref(hints), m, n, k, C.c_uint64(sid))
+    with_split = lambda sid, sk: (sid & ~(0xF << 60)) | (sk << 60)
+    stream = next(i for i in ids if (i >> 48) & 0xF == 0)
+    tiled = next(i for i in ids if (i >> 48) & 0xF == 8)
+    native = next(i for i in ids if (i >> 48) & 0xF == 9)
+    assert need(stream) == 0 and need(tiled) == 0
+    assert need(with_split(stream, 2)) == 2 * m * n * 4 and need(with_split(tiled, 4)) == 4 * m * n * 4
+    nat = _lib.lib.petit_native_workspace_bytes(m, k)
+    assert need(native) == nat == m * k + m * k // 32
+    assert need(with_split(native, 2)) == ((nat + 255) & ~255) + 2 * m * n * 4
+    assert need(0x1234) == 0
+
+
 def test_heuristic_stays_close_to_the_measured_best():
     """Where the arch table has no row the heuristic decides: replayed (table disabled) against every case of the
     committed MI355X sweeps its median must stay within 1.03x of the best measured solution, 90 % of the cases within 1.2x, the worst

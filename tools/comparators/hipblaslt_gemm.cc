@@ -1,0 +1,85 @@
+// hipblaslt_gemm.cc -- the dense 16-bit GEMM comparator of bench.py / tools/tune.py: C[m][n] = A[m][k] . W[n][k]^T through
+// hipBLASLt with f32 compute, i.e. what the reference benchmarks its kernels against
+// (tools/benchmarks/matmul/rocm/matmul_hipblaslt.cc:103-123 for the problem description, :249-263 for the call;
+// fp4/gemm_fp4_fp16_rocm_test.cc:97-164 uses the same layout).  Written against the public hipBLASLt C API; the
+// operand order is the usual row-major trick: the library sees column-major C^T[n][m] = op_T(W)[n][k] . A^T[k][m].
+// NOT part of the product: a measurement aid, built by __graft_entry__.build() into tools/comparators/.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+constexpr size_t kWorkspace = 32u << 20; // matmul_hipblaslt.cc:25
+
+struct Gemm {
+    hipblasLtHandle_t handle = nullptr;
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t la = nullptr, lw = nullptr, lc = nullptr;
+    hipblasLtMatmulAlgo_t algo;
+    void *workspace = nullptr;
+    size_t workspace_bytes = 0;
+};
+#define HBL_TRY(x)                                                     \
+    do {                                                               \
+        if ((x) != HIPBLAS_STATUS_SUCCESS) {                           \
+            fprintf(stderr, "hipblaslt_gemm: %s failed\n", #x);        \
+            return nullptr;                                            \
+        }                                                              \
+    } while (0)
+} // namespace
+
+extern "C" {
+
+// is_bf16: 1 = bf16 operands and output, 0 = fp16.  Returns an opaque handle or NULL.
+void *hbl_create(int m, int n, int k, int is_bf16) {
+    Gemm *g = new Gemm;
+    const hipDataType t = is_bf16 ? HIP_R_16BF : HIP_R_16F;
+    const hipblasOperation_t trans = HIPBLAS_OP_T;
+    HBL_TRY(hipblasLtCreate(&g->handle));
+    HBL_TRY(hipblasLtMatmulDescCreate(&g->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+    HBL_TRY(hipblasLtMatmulDescSetAttribute(g->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &trans, sizeof(trans)));
+    HBL_TRY(hipblasLtMatrixLayoutCreate(&g->lw, t, k, n, k)); // W row-major [n][k] = column-major k x n
+    HBL_TRY(hipblasLtMatrixLayoutCreate(&g->la, t, k, m, k)); // A row-major [m][k] = column-major k x m
+    HBL_TRY(hipblasLtMatrixLayoutCreate(&g->lc, t, n, m, n)); // C row-major [m][n] = column-major n x m
+    if (hipMalloc(&g->workspace, kWorkspace) != hipSuccess)
+        return nullptr;
+    g->workspace_bytes = kWorkspace;
+    hipblasLtMatmulPreference_t pref = nullptr;
+    HBL_TRY(hipblasLtMatmulPreferenceCreate(&pref));
+    HBL_TRY(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &kWorkspace, sizeof(kWorkspace)));
+    hipblasLtMatmulHeuristicResult_t res[1];
+    int found = 0;
+    HBL_TRY(hipblasLtMatmulAlgoGetHeuristic(g->handle, g->desc, g->lw, g->la, g->lc, g->lc, pref, 1, res, &found));
+    hipblasLtMatmulPreferenceDestroy(pref);
+    if (found < 1) {
+        fprintf(stderr, "hipblaslt_gemm: no algorithm for m=%d n=%d k=%d\n", m, n, k);
+        return nullptr;
+    }
+    g->algo = res[0].algo;
+    return g;
+}
+
+// Enqueue one GEMM on `stream`.  0 on success.
+int hbl_run(void *handle, const void *a, const void *w, void *c, void *stream) {
+    Gemm *g = static_cast<Gemm *>(handle);
+    const float alpha = 1.0f, beta = 0.0f;
+    return (int)hipblasLtMatmul(g->handle, g->desc, &alpha, w, g->lw, a, g->la, &beta, c, g->lc, c, g->lc, &g->algo,
+                                g->workspace, g->workspace_bytes, (hipStream_t)stream);
+}
+
+void hbl_destroy(void *handle) {
+    Gemm *g = static_cast<Gemm *>(handle);
+    if (!g)
+        return;
+    hipblasLtMatrixLayoutDestroy(g->la);
+    hipblasLtMatrixLayoutDestroy(g->lw);
+    hipblasLtMatrixLayoutDestroy(g->lc);
+    hipblasLtMatmulDescDestroy(g->desc);
+    hipblasLtDestroy(g->handle);
+    (void)hipFree(g->workspace);
+    delete g;
+}
+
+} // extern "C"
