@@ -97,13 +97,21 @@ def cpu_baseline(a, gs, q, s, budget_s: float = 10.0):
     }
 
 
-def measure_cells(dev, stream, budget_s: float) -> dict:
+def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
     """The whole metric: M in {1, 8, 16, 512} x the four Llama-3-70B linears, bf16 x NVFP4 through solution_id = -1;
     at M = 512 also the native-FP4 kernels (bf16 x MXFP4, opt-in accuracy class) and hipBLASLt bf16 on a dense weight."""
     import benchlib as BL
     from petit_kernel import _lib
     t0 = time.time()
-    cells, notes = [], []
+    notes = []
+
+    class Cells(list):
+        def append(self, cell):          # every finished cell goes to the parent at once (a GPU fault kills this process)
+            super().append(cell)
+            if sink is not None:
+                sink.write(json.dumps(cell) + "\n")
+                sink.flush()
+    cells = Cells()
     auto = _lib.PETIT_SOLUTION_AUTO
     for shape in ("qkv", "o", "gate_up", "down"):
         n, k = BL.LLAMA70B[shape]
@@ -114,6 +122,7 @@ def measure_cells(dev, stream, budget_s: float) -> dict:
                 break
             g = BL.Gemm(w, m, torch.bfloat16, dev)
             sid = g.default_solution()
+            print(f"[bench] cell {shape} M={m} 0x{sid:x}", file=sys.stderr, flush=True)
             r = g.time(auto, stream, reps=7)
             hbm = m <= 16
             cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x nvfp4", "us": round(r["us"], 3),
@@ -130,6 +139,7 @@ def measure_cells(dev, stream, budget_s: float) -> dict:
         wm = BL.Weights("mx", n, k, 1280, dev)
         gm = BL.Gemm(wm, m, torch.bfloat16, dev)
         sid = gm.default_solution()
+        print(f"[bench] cell {shape} M={m} mx 0x{sid:x}", file=sys.stderr, flush=True)
         r = gm.time(auto, stream, reps=5)
         cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x mxfp4", "us": round(r["us"], 3),
                       "us_min": round(r["us_min"], 3), "GB/s": round(r["gbs"], 1), "TFLOPS": round(r["tflops"], 2),
@@ -143,6 +153,7 @@ def measure_cells(dev, stream, budget_s: float) -> dict:
                     if sk > 1 and n * m > 8192 * 512 * 2:
                         continue   # K split only pays where the plain grid under-fills the chip
                     cand = (nsid & ~(0xF << 60)) | (sk << 60)
+                    print(f"[bench] cell {shape} M={m} native 0x{cand:x}", file=sys.stderr, flush=True)
                     rr = gm.time(cand, stream, reps=3, launches=10)
                     if best is None or rr["us"] < best[1]["us"]:
                         best = (cand, rr)
@@ -162,6 +173,7 @@ def measure_cells(dev, stream, budget_s: float) -> dict:
         del wm, gm
         torch.cuda.empty_cache()
         try:
+            print(f"[bench] cell {shape} M={m} hipBLASLt", file=sys.stderr, flush=True)
             hb = BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev)
             hb.check()
             rr = hb.time(stream, reps=5)
@@ -207,6 +219,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cells", action="store_true", help="headline only (skip the M x shape table)")
     ap.add_argument("--cells-budget-s", type=float, default=150.0)
+    ap.add_argument("--cells-child", default="", help=argparse.SUPPRESS)   # internal: run the cell table, append JSON lines to this file
     ap.add_argument("--rotate-mb", type=int, default=1280,
                     help="rotate over at least this many MB of distinct weights; measured on MI355X: per-launch time "
                          "keeps rising until ~1.3 GB (8.3 us at 40 MB, 8.7 at 320 MB, 9.2 at >= 1.3 GB), i.e. the 256 MB "
@@ -218,6 +231,13 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.cells_child:
+        torch.cuda.set_device(0)
+        with open(args.cells_child, "a") as sink:
+            meta = measure_cells(torch.device("cuda", 0), torch.cuda.Stream(), args.cells_budget_s, sink)
+            meta.pop("cells")
+            sink.write(json.dumps({"_meta": meta}) + "\n")
+        return
     # one process per GPU; more ranks than GPUs (only useful to smoke-test this flow on a 1-GPU box) wrap around
     dev_index = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
@@ -371,6 +391,7 @@ def main() -> None:
                 "us_per_launch": ms_per_step * 1e3,
             },
         }
+        print(f"[bench] headline {ms_per_step * 1e3:.3f} us/step", file=sys.stderr, flush=True)
         if world == 1:
             with torch.cuda.stream(stream):
                 line["host_us_per_call"] = {"ctypes": host_overhead(step)}
@@ -386,10 +407,27 @@ def main() -> None:
         del packed
         torch.cuda.empty_cache()
         if world == 1 and not args.no_cells:
-            try:
-                line.update(measure_cells(dev, stream, args.cells_budget_s))
-            except Exception as exc:  # noqa: BLE001 -- the table must never cost the headline line
-                line["cells_error"] = repr(exc)
+            # the table runs in a CHILD process that reports every finished cell at once: a fault in any one kernel (or in
+            # the vendor comparator) costs that cell, never the headline line or the cells already measured
+            import subprocess
+            import tempfile
+            with tempfile.NamedTemporaryFile("r", suffix=".jsonl", dir=str(ROOT / "gpurun_out") if (ROOT / "gpurun_out").is_dir() else None) as tf:
+                try:
+                    rc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cells-child", tf.name, "--cells-budget-s",
+                                         str(args.cells_budget_s)], timeout=args.cells_budget_s + 90, stdout=subprocess.DEVNULL).returncode
+                except subprocess.TimeoutExpired:
+                    rc = "timeout"
+                cells, meta = [], {}
+                for ln in Path(tf.name).read_text().splitlines():
+                    rec = json.loads(ln)
+                    if "_meta" in rec:
+                        meta = rec["_meta"]
+                    else:
+                        cells.append(rec)
+                line["cells"] = cells
+                line.update(meta)
+                if rc != 0:
+                    line["cells_error"] = f"cell process ended with {rc} after {len(cells)} cells (see stderr)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a, gs, qs[0], ss[0])
         print(json.dumps(line), flush=True)

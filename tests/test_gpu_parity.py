@@ -46,7 +46,7 @@ def to_f32(b: np.ndarray, is_bf16: bool) -> np.ndarray:
     return O.bf16_bits_to_f32(b) if is_bf16 else O.f16_bits_to_f32(b)
 
 
-def check_gemm(c_bits, ref_f32, is_bf16, sum_abs=None):
+def check_gemm(c_bits, ref_f32, is_bf16, sum_abs=None, sum_abs_coef=1e-5):
     """sum_abs: optional sum_k |a||w| per output.  With e8m0 block scales the products span many
     binades, and ANY f32-accumulating implementation carries ~sqrt(K)*2^-24 of that sum as absolute
     error; where the true result cancels to ~0 that, not 1e-2, is the honest bound."""
@@ -56,9 +56,14 @@ def check_gemm(c_bits, ref_f32, is_bf16, sum_abs=None):
     err = np.abs(c - ref)
     bound = np.maximum(1e-2, 1e-2 * np.abs(ref))
     if sum_abs is not None:
-        bound = np.maximum(bound, 1e-5 * sum_abs)
+        bound = np.maximum(bound, sum_abs_coef * sum_abs)
     assert np.isfinite(c[fin]).all()
-    assert (err[fin] <= bound[fin]).all(), f"max err {err[fin].max()} at ref {ref[fin][err[fin].argmax()]}"
+    if not (err[fin] <= bound[fin]).all():
+        ratio = np.where(fin, err / bound, 0.0)
+        w = np.unravel_index(ratio.argmax(), ratio.shape)
+        raise AssertionError(f"{int((ratio > 1).sum())} of {ratio.size} outputs out of bound; worst at {w}: got {c[w]!r} ref {ref[w]!r} "
+                             f"err {err[w]:.4g} bound {bound[w]:.4g}" + (f" sum|a||w| {sum_abs[w]:.4g}" if sum_abs is not None else "")
+                             + f"; largest err {err[fin].max():.4g} at ref {ref[fin][err[fin].argmax()]:.4g}")
     # and much tighter on average: one 16-bit rounding of an f32-accumulated sum
     rel = err[fin] / np.maximum(np.abs(ref[fin]), 1e-3)
     assert np.median(rel) < (2 ** -8 if is_bf16 else 2 ** -11)
@@ -691,6 +696,13 @@ def test_adversarial_activations_every_solution(pk, kind, is_bf16, m, profile):
     a, q = adversarial_activations(m, k, q, is_bf16, 4000 + m, profile)
     ref = oracle_ref(kind, a, is_bf16, q, s, gs)
     sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
+    coef = 1e-5
+    if kind == "nv" and profile == 1:
+        # outputs whose 2^36-sized terms cancel to 1e-6 of their size: what remains is the f32 accumulation floor of
+        # ANY implementation that sums in f32 (the reference's MFMA accumulators included): a few ulp of the largest
+        # partial sum (measured: 7e4 on terms of 1e12 = 0.6 ulp).  2^-20 of sum|a||w|, 10x tighter than the MX allowance.
+        dq = np.abs(O.dequant_nvfp4(q, s))
+        sum_abs, coef = (np.abs(to_f32(a, is_bf16)) @ dq.T) * gs, 2.0 ** -20
     assert np.isfinite(ref).all()
     h = pk.PetitSolutionHints()
     h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
@@ -701,7 +713,7 @@ def test_adversarial_activations_every_solution(pk, kind, is_bf16, m, profile):
     for sid in [-1] + list(sols):
         c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid)
         try:
-            check_gemm(c, ref, is_bf16, sum_abs)
+            check_gemm(c, ref, is_bf16, sum_abs, coef)
         except AssertionError as exc:
             raise AssertionError(f"solution {sid:#x}: {exc}") from None
 
@@ -965,10 +977,20 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
         native = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 32) & 7 == 2]
         assert native
         pk.ops.set_workspace(None)
-        with pytest.raises(RuntimeError, match="No kernel implementation"):
-            run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, native[0])       # no workspace registered
+        # the C ABI without any scratch (none registered, none passed) refuses a native kernel; the Python layer hands
+        # every call its own scratch, and a registered workspace (round-1 style) is honoured when there is one
+        from petit_kernel import _lib
+        import ctypes as C
+        ch = _lib.SolutionHints(_lib.CXX_DTYPE_BF16 if is_bf16 else _lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1,
+                                _lib.CXX_DTYPE_BF16 if is_bf16 else _lib.CXX_DTYPE_FP16, 0)
+        dummy = torch.zeros(max(m * k, n * k, m * n), dtype=torch.int32, device=DEV)
+        assert _lib.lib.petit_gemm_mxfp4_fp16_grid(dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(), dummy.data_ptr(),
+                                                   m, n, k, C.byref(ch), C.c_uint64(native[0]), None) == _lib.PETIT_ERROR_KERNEL_SHAPE
+        assert pk.ops.workspace_bytes(h, m, n, k, native[0]) == pk.ops.native_workspace_bytes(m, k)
+        c_percall = run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, native[0])      # per-call scratch
         ws = torch.empty(pk.ops.native_workspace_bytes(m, k), dtype=torch.uint8, device=DEV)
         pk.ops.set_workspace(ws)
+        assert np.array_equal(c_percall, run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, native[0]))
         a_f32 = to_f32(a_bits, is_bf16)
         a_q = quantize_act_mxfp8(a_f32)
         dq = O.dequant_mxfp4(q, s)

@@ -203,24 +203,23 @@ class HipblasLtGemm:
     def time(self, stream, reps: int = 7, launches: int = 0) -> dict:
         flops = 2.0 * self.m * self.n * self.k
         launches = launches or int(max(5, min(100, 3000.0 / max(flops / (BF16_PEAK_TFLOPS * 1e6), 1.0))))
-        mode = "hip graph replay"
-        try:
-            us = time_graph(self.launch, launches, reps, stream)
-        except Exception:  # noqa: BLE001 -- capture refused by the library: time eager launches (>= 50 us each, GPU-bound)
-            mode = "eager"
-            us = []
-            with torch.cuda.stream(stream):
-                for _ in range(3):
-                    self.launch(0)
+        # eager launches (each >= 50 us of GPU work against ~5 us of host work per call: the GPU queue never runs dry);
+        # hipBLASLt under stream capture faulted on one shape on this stack, and the comparator must not be fragile
+        mode = "eager, back-to-back"
+        us = []
+        with torch.cuda.stream(stream):
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.02:
+                self.launch(0)
                 stream.synchronize()
-                for _ in range(reps):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    for i in range(launches):
-                        self.launch(i)
-                    e1.record(stream)
-                    stream.synchronize()
-                    us.append(e0.elapsed_time(e1) * 1e3 / launches)
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for i in range(launches):
+                    self.launch(i)
+                e1.record(stream)
+                stream.synchronize()
+                us.append(e0.elapsed_time(e1) * 1e3 / launches)
         med = median(us)
         return {"us": med, "us_min": min(us), "tflops": flops / med / 1e6, "launches": launches, "reps": reps, "launch": mode}
 

@@ -49,15 +49,23 @@ void *hbl_create(int m, int n, int k, int is_bf16) {
     hipblasLtMatmulPreference_t pref = nullptr;
     HBL_TRY(hipblasLtMatmulPreferenceCreate(&pref));
     HBL_TRY(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &kWorkspace, sizeof(kWorkspace)));
-    hipblasLtMatmulHeuristicResult_t res[1];
+    hipblasLtMatmulHeuristicResult_t res[8];
     int found = 0;
-    HBL_TRY(hipblasLtMatmulAlgoGetHeuristic(g->handle, g->desc, g->lw, g->la, g->lc, g->lc, pref, 1, res, &found));
+    HBL_TRY(hipblasLtMatmulAlgoGetHeuristic(g->handle, g->desc, g->lw, g->la, g->lc, g->lc, pref, 8, res, &found));
     hipblasLtMatmulPreferenceDestroy(pref);
-    if (found < 1) {
-        fprintf(stderr, "hipblaslt_gemm: no algorithm for m=%d n=%d k=%d\n", m, n, k);
+    // the first candidate the library itself declares usable within the workspace
+    int pick = -1;
+    for (int i = 0; i < found && pick < 0; ++i)
+        if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= kWorkspace)
+            pick = i;
+    if (pick < 0) {
+        fprintf(stderr, "hipblaslt_gemm: no algorithm for m=%d n=%d k=%d (found %d)\n", m, n, k, found);
         return nullptr;
     }
-    g->algo = res[0].algo;
+    if (getenv("HBL_VERBOSE"))
+        fprintf(stderr, "hipblaslt_gemm: m=%d n=%d k=%d: candidate %d of %d, workspace %zu B\n", m, n, k, pick, found,
+                (size_t)res[pick].workspaceSize);
+    g->algo = res[pick].algo;
     return g;
 }
 
