@@ -180,8 +180,8 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         for (int i = 0; i < fam.count; ++i) {
             const SolutionEntry &e = fam.entries[i];
             const StreamShape &s = e.shape;
-            if (!entry_fits(e, m, k) || s.am == kNativeAm || (need_pairs && !act_ok(e)))
-                continue; // (never the native-FP4 kernels: different accuracy class)
+            if (!entry_fits(e, m, k) || s.am == kNativeAm || s.am == kWideAm || (need_pairs && !act_ok(e)))
+                continue; // (never the native-FP4 kernels: different accuracy class; the 32x32 kernels come from the arch table)
             double us;
             if (s.am == kTiledAm) {
                 us = tiled_cost_us(e, m, n, k, arch.num_cus);
@@ -222,7 +222,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         if (!entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
             continue;
         const StreamShape &s = e.shape;
-        if (s.mt != want_mt || s.am == kTiledAm || s.am == kNativeAm)
+        if (s.mt != want_mt || s.am == kTiledAm || s.am == kNativeAm || s.am == kWideAm)
             continue;
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
@@ -243,7 +243,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
             if (entry_fits(fam.entries[i], m, k) && fam.entries[i].shape.am != kTiledAm &&
-                fam.entries[i].shape.am != kNativeAm && (!need_pairs || act_ok(fam.entries[i])) &&
+                fam.entries[i].shape.am != kNativeAm && fam.entries[i].shape.am != kWideAm && (!need_pairs || act_ok(fam.entries[i])) &&
                 (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
     }
@@ -592,6 +592,12 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         snprintf(buf, len, "native-fp4 %sxmxfp4 (activations -> mxfp8) ks%d mt%d ntw%d waves%d d%d  (wg tile %dx%d, %d threads)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", s.ks, s.mt, s.nt, s.wn, s.d, 16 * s.mt, 16 * s.wn * s.nt,
                  64 * s.wn);
+        return kOk;
+    }
+    if (s.am == kWideAm) {
+        snprintf(buf, len, "wide32 %sx%s ks%d mb%d np%d waves%d d%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x16 mfma)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
+                 s.mt, s.nt / 2, s.wn, s.d, s.pa, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
         return kOk;
     }
     if (s.am == kTiledAm) {

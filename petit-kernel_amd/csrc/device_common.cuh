@@ -242,6 +242,39 @@ __device__ __forceinline__ unsigned physical_tile(unsigned l, unsigned ntiles, u
     return act ? (l >> 1) + (l & 1u) * (ntiles >> 1) : l;
 }
 
+// Large-M kernels: which (n-block, m-block) tile this workgroup computes.  Workgroups are dispatched round-robin over
+// the 8 XCDs (observed: block b runs on XCD b % 8, each XCD with a private 4 MiB L2), so with the plain mapping the
+// workgroups that share a weight panel sit on 8 different L2s and every one of them pulls the panel from HBM.  The
+// XCD-aware raster gives each XCD a contiguous chunk of the tile list, m-blocks fastest: the tiles an XCD runs at the
+// same time are a few weight panels x ALL their m-blocks, so a panel leaves HBM once per XCD-chunk instead of once per
+// m-block (M = 512, gate_up: 1.06 GB -> ~0.3 GB per launch).  A pure speed choice: any placement computes the same.
+__device__ __forceinline__ void tile_of_block(unsigned flags, unsigned &bn, unsigned &bm) {
+    const unsigned nx = gridDim.x, ny = gridDim.y;
+    if (!(flags & kFlagXcdRaster)) {
+        bn = blockIdx.x, bm = blockIdx.y;
+        return;
+    }
+    const unsigned b = blockIdx.y * nx + blockIdx.x, nwg = nx * ny;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, idx = b >> 3;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; // bijective for any nwg
+    bn = t / ny, bm = t - bn * ny;
+}
+
+// Two waves share a SIMD in the 2-workgroups-per-CU kernels, run the same phases (unpack burst, MFMA burst, barrier) and,
+// sharing the matrix pipe fairly, fall into lock step: both unpack at the same time (matrix pipe idle), both issue MFMAs
+// at the same time (VALU idle).  A static priority by the parity of the wave's hardware slot breaks the convoy: the
+// favoured wave runs its MFMA burst at full rate while the other fills every gap, so one wave's VALU work overlaps the
+// other's MFMAs.  (s_setprio is a scalar instruction; the slot id is wave-uniform by construction.)
+__device__ __forceinline__ void stagger_priority(unsigned flags) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (flags & kFlagPrio) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11)); // wave_id[3:0]
+        if (slot & 1u)
+            __builtin_amdgcn_s_setprio(1);
+    }
+#endif
+}
+
 // Scale record of one span for one n-tile: KS*2 bytes (NV) / KS bytes (MX).
 template <int FMT, int KS> struct ScaleRec {
     static constexpr int kBytes = (FMT == kFmtNv ? 2 : 1) * KS;

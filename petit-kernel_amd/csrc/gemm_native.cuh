@@ -133,8 +133,11 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     const unsigned ktiles = p.k / kTileK;
     const unsigned nspans = ktiles / KS;
     const unsigned ntiles = p.n / kTileN;
-    const unsigned nt0 = (blockIdx.x * WAVES + wave) * NTW;
-    const unsigned m0 = blockIdx.y * Cfg::BM;
+    unsigned bn, bm;
+    tile_of_block(p.flags, bn, bm);
+    stagger_priority(p.flags);
+    const unsigned nt0 = (bn * WAVES + wave) * NTW;
+    const unsigned m0 = bm * Cfg::BM;
     // K slice of this workgroup (gridDim.z > 1: see gemm_tiled.cuh)
     const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
     const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);

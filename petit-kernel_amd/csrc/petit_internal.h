@@ -42,7 +42,9 @@ struct GemmArgs {
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
     unsigned m, n, k;
     unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))
+    unsigned flags;          // large-M kernels: kFlagPrio | kFlagXcdRaster (launch_flags(), stream_tu.inc)
 };
+enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u };
 
 // repack.hip
 int repack_weights(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);

@@ -29,7 +29,9 @@
 //                                 bit 35 set when the activations are fp16),
 //                                 8 = the tiled large-M kernel (gemm_tiled.cuh), whose
 //                                 fields read: tile_m = MT, warp_partition_n = WAVES,
-//                                 bits 52-55 = NTW, warp_partition_k = 1
+//                                 bits 52-55 = NTW, warp_partition_k = 1;
+//                                 12 = the 32x32x16-MFMA large-M kernel (gemm_wide.cuh):
+//                                 tile_m = MB (m32-blocks), bits 52-55 = 2 NP
 //   bits 52-55  [was padding]     NT  n-tiles per wave
 //   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
 //   bits 60-63  [was padding]     split-K across workgroups (gridDim.z), >= 1
@@ -55,12 +57,16 @@ constexpr int kTiledAm = -1;
 // the native-FP4 kernels (gemm_native.cuh): MXFP4 weights straight into the block-scaled MFMA,
 // activations quantised to MXFP8; opt-in, never a default
 constexpr int kNativeAm = -2;
+// the 32x32x16-MFMA large-M kernel (gemm_wide.cuh): code 12; fields read tile_m = MB (m32-blocks), bits 52-55 = n-tiles
+// per wave (2 NP), warp_partition_n = WAVES
+constexpr int kWideAm = -3;
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
 // per-span block floating point (Bf16Bfp in gemm_stream.cuh); codes 5 / 6 / 7
 constexpr int kBfpAm = 100;
 constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {
     return am == kNativeAm ? 9u
+           : am == kWideAm  ? 12u
            : am == kTiledAm ? 8u
            : am == 0        ? 0u
            : am == 8        ? 10u

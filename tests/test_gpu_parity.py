@@ -576,7 +576,7 @@ def test_fused_bias_epilogue(pk, kind, is_bf16, m, n, k, splitk):
     if splitk > 1:
         ws = torch.empty(splitk * m * n, dtype=torch.float32, device=DEV)
         pk.ops.set_workspace(ws)
-        sols = [(sid & ~(0xF << 60)) | (splitk << 60) for sid in sols if (sid >> 48) & 0xF not in (8, 9)][:6]
+        sols = [(sid & ~(0xF << 60)) | (splitk << 60) for sid in sols if (sid >> 48) & 0xF not in (8, 9, 12)][:6]
     try:
         sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
         for sid in [-1] + list(sols):
@@ -919,8 +919,9 @@ def test_m512_full_size_tiled_and_native(pk, kind, shape):
     pk.ops.enable_native_fp4(True)
     try:
         sols = pk.ops.get_fp4_solutions(P.hints(True), m, n, k)
-        tiled = [sid for sid in sols if (sid >> 48) & 0xF == 8]
+        tiled = [sid for sid in sols if (sid >> 48) & 0xF in (8, 12)]       # 16x16x32 tiled and 32x32x16 wide kernels
         native = [sid for sid in sols if (sid >> 32) & 7 == 2]
+        assert any((sid >> 48) & 0xF == 12 for sid in tiled)
         assert tiled
         for sid in tiled:
             P.check_sampled(P.run(a, True, sid), a, True, f"tiled {sid:#x}")

@@ -116,8 +116,11 @@ def main():
                         launch(0)
                         torch.cuda.synchronize()
                         err = (g.c.float() - c_ref).abs()
-                        tol = 1e-2 if not is_native(sid) else 6e-2   # native: activations quantised (own accuracy class)
-                        bad = err > torch.clamp(c_ref.abs() * tol, min=tol * max(1.0, c_ref.abs().mean().item() if is_native(sid) else 1.0))
+                        # two exact kernels differ by f32 summation order and one 16-bit rounding: 1 % of the value, or 2 % of
+                        # the output rms where the value itself cancels; a wrong tile / layout is off by ~ the rms itself.
+                        # Native kernels quantise the activations (own accuracy class): 6 % / 12 %.
+                        rel, floor = (1e-2, 2e-2) if not is_native(sid) else (6e-2, 12e-2)
+                        bad = err > torch.clamp(c_ref.abs() * rel, min=floor * c_ref.pow(2).mean().sqrt().item())
                         if bad.any():
                             dropped.append({"solution": f"0x{sid:x}", "desc": _lib.describe_solution(sid),
                                             "mismatches": int(bad.sum()), "max_err": float(err.max())})
