@@ -147,27 +147,27 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                       "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"})
         _lib.lib.petit_enable_native_fp4(1)
         try:
-            best = None
-            for nsid in [s for s in gm.solutions() if (s >> 48) & 0xF == 9]:
-                for sk in (1, 2):
-                    if sk > 1 and n * m > 8192 * 512 * 2:
-                        continue   # K split only pays where the plain grid under-fills the chip
-                    cand = (nsid & ~(0xF << 60)) | (sk << 60)
-                    print(f"[bench] cell {shape} M={m} native 0x{cand:x}", file=sys.stderr, flush=True)
-                    rr = gm.time(cand, stream, reps=3, launches=10)
-                    if best is None or rr["us"] < best[1]["us"]:
-                        best = (cand, rr)
-            if best:
-                cand, rr = best
-                rr = gm.time(cand, stream, reps=5)
-                fp4x4 = (cand >> 32) & 0x4 != 0
-                peak = BL.FP4_PEAK_TFLOPS if fp4x4 else BL.FP8_PEAK_TFLOPS
-                cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x mxfp4 native (opt-in)",
-                              "us": round(rr["us"], 3), "us_min": round(rr["us_min"], 3), "TFLOPS": round(rr["tflops"], 2),
-                              "bound": "mfma", "peak_TFLOPS": peak, "frac": round(rr["tflops"] / peak, 4),
-                              "frac_of_fp4_peak": round(rr["tflops"] / BL.FP4_PEAK_TFLOPS, 4),
-                              "solution": f"0x{cand:x} {_lib.describe_solution(cand)}",
-                              "note": "both launches (activation quantiser + GEMM) timed"})
+            # one cell per activation format: MXFP8 (mfma_type 2, FP8-rate instruction) and MXFP4 (6, FP4 x FP4)
+            for act_code, act_name, peak in ((2, "mxfp8", BL.FP8_PEAK_TFLOPS), (6, "mxfp4", BL.FP4_PEAK_TFLOPS)):
+                best = None
+                for nsid in [s for s in gm.solutions() if (s >> 48) & 0xF in (9, 13) and (s >> 32) & 7 == act_code]:
+                    for sk in (1, 2):
+                        if sk > 1 and n * m > 8192 * 512 * 2:
+                            continue   # K split only pays where the plain grid under-fills the chip
+                        cand = (nsid & ~(0xF << 60)) | (sk << 60)
+                        print(f"[bench] cell {shape} M={m} native 0x{cand:x}", file=sys.stderr, flush=True)
+                        rr = gm.time(cand, stream, reps=3, launches=10)
+                        if best is None or rr["us"] < best[1]["us"]:
+                            best = (cand, rr)
+                if best:
+                    cand, rr = best
+                    rr = gm.time(cand, stream, reps=5)
+                    cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": f"bf16 x mxfp4 native, activations -> {act_name} (opt-in)",
+                                  "us": round(rr["us"], 3), "us_min": round(rr["us_min"], 3), "TFLOPS": round(rr["tflops"], 2),
+                                  "bound": "mfma", "peak_TFLOPS": peak, "frac": round(rr["tflops"] / peak, 4),
+                                  "frac_of_fp4_peak": round(rr["tflops"] / BL.FP4_PEAK_TFLOPS, 4),
+                                  "solution": f"0x{cand:x} {_lib.describe_solution(cand)}",
+                                  "note": "both launches (activation quantiser + GEMM) timed"})
         finally:
             _lib.lib.petit_enable_native_fp4(0)
         del wm, gm

@@ -96,7 +96,7 @@ uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
 // bytes of scratch a (kernel, split) needs for (m, n, k): [native: quantised activations, 256-B aligned][slabs]
 uint64_t workspace_need(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k) {
     const uint64_t slabs = splitk_bytes(splitk, m, n);
-    if (e.shape.am == kNativeAm)
+    if (is_native_am(e.shape.am)) // (sized for MXFP8 activations; the MXFP4 form needs less)
         return slabs ? native_ws_aligned(m, k) + slabs : native_ws_bytes(m, k);
     return slabs;
 }
@@ -180,7 +180,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         for (int i = 0; i < fam.count; ++i) {
             const SolutionEntry &e = fam.entries[i];
             const StreamShape &s = e.shape;
-            if (!entry_fits(e, m, k) || s.am == kNativeAm || s.am == kWideAm || (need_pairs && !act_ok(e)))
+            if (!entry_fits(e, m, k) || is_native_am(s.am) || s.am == kWideAm || (need_pairs && !act_ok(e)))
                 continue; // (never the native-FP4 kernels: different accuracy class; the 32x32 kernels come from the arch table)
             double us;
             if (s.am == kTiledAm) {
@@ -222,7 +222,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         if (!entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
             continue;
         const StreamShape &s = e.shape;
-        if (s.mt != want_mt || s.am == kTiledAm || s.am == kNativeAm || s.am == kWideAm)
+        if (s.mt != want_mt || s.am == kTiledAm || is_native_am(s.am) || s.am == kWideAm)
             continue;
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
@@ -243,7 +243,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
             if (entry_fits(fam.entries[i], m, k) && fam.entries[i].shape.am != kTiledAm &&
-                fam.entries[i].shape.am != kNativeAm && fam.entries[i].shape.am != kWideAm && (!need_pairs || act_ok(fam.entries[i])) &&
+                !is_native_am(fam.entries[i].shape.am) && fam.entries[i].shape.am != kWideAm && (!need_pairs || act_ok(fam.entries[i])) &&
                 (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
     }
@@ -251,7 +251,9 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
 }
 
 unsigned entry_mfma(const Family &fam, const SolutionEntry &e) {
-    if (e.shape.am == kNativeAm)
+    if (e.shape.am == kNative32Am && e.shape.pa == 2) // activations quantised to MXFP4
+        return e.a_type == kDataTypeFp16 ? kMfmaFp4ActFp16 : kMfmaFp4;
+    if (is_native_am(e.shape.am))
         return e.a_type == kDataTypeFp16 ? kMfmaFp8ActFp16 : kMfmaFp8;
     return fam.mfma;
 }
@@ -304,7 +306,7 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
     if (tuned) {
         c.entry = find_entry(fam, tuned);
         c.splitk = solution_splitk(tuned);
-        if (c.entry && (c.entry->shape.am == kNativeAm || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
+        if (c.entry && (is_native_am(c.entry->shape.am) || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
                         (act && (!act_ok(*c.entry) || c.splitk != 1))))
             c.entry = nullptr;
     }
@@ -486,7 +488,7 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
         for (int i = 0; i < fam.count; ++i) {
             if (!entry_fits(fam.entries[i], m, k))
                 continue;
-            if (fam.entries[i].shape.am == kNativeAm && !native_enabled())
+            if (is_native_am(fam.entries[i].shape.am) && !native_enabled())
                 continue;
             if (sols && count < cap)
                 sols[count] = entry_id(fam, fam.entries[i]);
@@ -579,7 +581,7 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     if (!buf || len == 0)
         return kErrBadArgument;
     const unsigned elem_b = (unsigned)(id >> 28) & 0xf, mfma = (unsigned)(id >> 32) & 0xf;
-    const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8) ? kDataTypeBf16 : kDataTypeFp16;
+    const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8 || mfma == kMfmaFp4) ? kDataTypeBf16 : kDataTypeFp16;
     const int b_type = elem_b == kElemBMxFp4 ? kDataTypeMxFp4e2m1 : kDataTypeFp4e2m1;
     Family fam;
     const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_entry(fam, id) : nullptr;
@@ -592,6 +594,12 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         snprintf(buf, len, "native-fp4 %sxmxfp4 (activations -> mxfp8) ks%d mt%d ntw%d waves%d d%d  (wg tile %dx%d, %d threads)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", s.ks, s.mt, s.nt, s.wn, s.d, 16 * s.mt, 16 * s.wn * s.nt,
                  64 * s.wn);
+        return kOk;
+    }
+    if (s.am == kNative32Am) {
+        snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%d d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt, s.nt / 2, s.wn, s.d,
+                 s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
         return kOk;
     }
     if (s.am == kWideAm) {

@@ -1,0 +1,432 @@
+// gemm_native32.cuh -- the native-FP4 path on the 32x32x64 block-scaled MFMA, with FP8 or FP4 activations.
+//
+// MXFP4 weights go RAW into v_mfma_scale_f32_32x32x64_f8f6f4 (zero unpack VALU); the 16-bit activations are quantised on
+// the fly by a first small kernel, either to MXFP8 (e4m3 elements + one e8m0 scale per 32 k: the instruction then runs at
+// the FP8 rate, 5 PFLOP/s dense) or to MXFP4 (e2m1 elements + e8m0 per 32 k: FP4 x FP4, the 10 PFLOP/s rate MI355X
+// quotes for its hardware FP4).  OPT-IN, like gemm_native.cuh: quantising activations is a different accuracy class
+// (e4m3: 2^-4 relative per element, e2m1: 2^-2), never chosen by solution_id = -1; ids carry mfma_type 2 (FP8
+// activations) or 6 (FP4 activations).  Exact-semantics + stated-tolerance tests: tests/test_gpu_parity.py.
+//
+// What differs from gemm_native.cuh (16x16x128, FP8 only):
+//  * 32x32x64 instruction: two neighbouring n-tiles are merged in registers with two lane swaps per packed word
+//    (merge_tiles, gemm_wide.cuh), P1 = the pair's 32 rows x k 0..63 of the tile, P2 = k 64..127 -- each IS the
+//    instruction's FP4 operand (lane (row, h): 32 consecutive k), and the merged span-record byte IS its per-lane
+//    E8M0 scale.  Half as many MFMAs per flop, half as many activation-fragment reads per flop.
+//  * a k-step is two groups (P1, P2); a group issues MB*NP MFMAs on MB*NP different accumulators while the fragments of
+//    the next group are read from LDS (no MFMA waits for the previous one, no fragment is waited for right after
+//    its request -- the 16x16 kernel did both and sat at 0.30 of the FP8 rate).
+// Operand layouts probed on gfx950 (tools/probes/mfma32_layout_probe.hip):
+//   FP4 operand (A and B)  lane (row|col = l%32, h = l/32): regs 0-3, k = 32h + 8*reg + nibble   (natural)
+//   FP8 operand (B)        lane (col, h): regs 0-3 k = 16h .. 16h+15, regs 4-7 k = 32 + 16h .. 32+16h+15
+//   scales                 the E8M0 byte of block b (k in [32b, 32b+32)) comes from lanes l/32 = b of the same row/column
+#pragma once
+
+#include "gemm_native.cuh"
+#include "gemm_wide.cuh"
+
+namespace petit_amd {
+
+// Workspace layout: qa[M][K * ACT / 8] bytes, then qs[M][K/32] E8M0 bytes.
+//   ACT = 8: per 128-k tile 128 bytes in the order [0-15][32-47][16-31][48-63][64-79][96-111][80-95][112-127] (16-k units),
+//            so that lane (m, h) finds its P1 operand at byte 32h and its P2 operand at byte 64 + 32h.
+//   ACT = 4: per 128-k tile 64 bytes, natural nibble order: P1 operand at byte 16h, P2 at 32 + 16h.
+template <int ACT> __host__ __device__ inline size_t native32_ws_bytes(unsigned m, unsigned k) {
+    return (size_t)m * (k / 8 * ACT) + (size_t)m * (k / 32);
+}
+
+// One thread = 8 consecutive k of one row; the 4 threads of a quad share one 32-k block.
+template <class AT, int ACT>
+__global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsigned char *ws, unsigned m, unsigned k) {
+    const size_t units = (size_t)m * (k / 8);
+    const unsigned row_bytes = k / 8 * ACT;
+    unsigned char *qa = ws;
+    unsigned char *qs = ws + (size_t)m * row_bytes;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
+        const unsigned row = (unsigned)(u / (k / 8)), c8 = (unsigned)(u % (k / 8)); // 8-element column
+        const u32x4 raw = reinterpret_cast<const u32x4 *>(a)[u];
+        float v[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = raw[d];
+            if constexpr (AT::kType == kDataTypeBf16) {
+                const unsigned lo = w << 16, hi = w & 0xffff0000u;
+                v[2 * d] = __builtin_bit_cast(float, lo);
+                v[2 * d + 1] = __builtin_bit_cast(float, hi);
+            } else {
+                const f16x2 p = __builtin_bit_cast(f16x2, w);
+                v[2 * d] = (float)p[0];
+                v[2 * d + 1] = (float)p[1];
+            }
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            amax = fmaxf(amax, fabsf(v[i]));
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        // E8M0 scale 2^(E - emax_elem) with E the exponent of the block maximum (OCP MX): emax_elem = 7 for e4m3 as
+        // gemm_native.cuh uses it (maximum lands in [128, 256) <= 448), 2 for e2m1 (maximum in [4, 8), above 6 saturates)
+        constexpr unsigned kEmax = ACT == 8 ? 7u : 2u;
+        const unsigned ebits = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+        unsigned sbyte = amax == 0.f ? 127u : (ebits > kEmax ? ebits - kEmax : 1u);
+        sbyte = sbyte > 254u ? 254u : sbyte;
+        const unsigned kt = c8 / 16, col16 = c8 % 16;
+        if constexpr (ACT == 8) {
+            const float inv = __builtin_bit_cast(float, (254u - sbyte) << 23); // 2^-(sbyte-127)
+            int q0 = 0, q1 = 0;
+            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, q0, false);
+            q0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, q0, true);
+            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, q1, false);
+            q1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, q1, true);
+            const unsigned u16 = col16 >> 1, half = col16 & 1u;
+            const unsigned pos = (u16 & 4u) | ((u16 & 1u) << 1) | ((u16 >> 1) & 1u);
+            uint2 o;
+            o.x = (unsigned)q0, o.y = (unsigned)q1;
+            *reinterpret_cast<uint2 *>(qa + (size_t)row * row_bytes + kt * 128 + pos * 16 + half * 8) = o;
+        } else {
+            // hardware RNE conversion to e2m1 with saturation: dst nibbles = cvt(src / scale)
+            const float scale = __builtin_bit_cast(float, sbyte << 23); // 2^(sbyte-127)
+            unsigned q = 0;
+            q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[0], v[1], scale, 0);
+            q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[2], v[3], scale, 1);
+            q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[4], v[5], scale, 2);
+            q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[6], v[7], scale, 3);
+            *reinterpret_cast<unsigned *>(qa + (size_t)row * row_bytes + kt * 64 + col16 * 4) = q;
+        }
+        if ((c8 & 3) == 0)
+            qs[(size_t)row * (k / 32) + c8 / 4] = (unsigned char)sbyte;
+    }
+}
+
+//   MB, NP, WAVES, D as in WideCfg; ACT = 8 (MXFP8 activations) or 4 (MXFP4 activations).
+//   KT   k-tiles per barrier ("stage"): the quantised activation tile is small (128 / 64 bytes per row and k-tile), and with
+//        zero unpack work a k-tile is only 2*MB*NP MFMAs, so one barrier per tile leaves the wave waiting on it.
+//   PF   stages requested ahead (NBUF = PF + 1 LDS stages): 1 = the next stage is requested at the top of a stage and waited
+//        for at its end; 2 = two ahead, in flight across the barrier (raw s_barrier + counted vmcnt, as gemm_wide.cuh PF = 2).
+//        Unlike the dequant kernels (power-limited) this kernel was latency-bound: a stage took the L2 round
+//        trip (~1900 cycles) for 512 cycles of MFMA work.
+template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1> struct Native32Cfg {
+    using AT = AT_;
+    static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, PF = PF_, NBUF = PF_ + 1;
+    static constexpr int kThreads = 64 * WAVES;
+    static constexpr int BM = 32 * MB;
+    static constexpr int kRowU4 = ACT;                        // 16-byte units per LDS row: 128 B (FP8) / 64 B (FP4)
+    static constexpr int kDataU4 = BM * kRowU4;               // one tile image
+    static constexpr int kScaleU4 = (BM + 3) / 4 < kThreads / 4 ? kThreads / 4 : (BM + 3) / 4; // one dword per row (wave-loads of 64)
+    static constexpr int kRowsPerLoad = 64 / kRowU4;          // rows one 1 KiB wave-load covers: 8 / 16
+    static constexpr int kDataLoads = BM / kRowsPerLoad / WAVES;
+    static_assert(ACT == 8 || ACT == 4, "activations are quantised to MXFP8 or MXFP4");
+    static_assert(KS % D == 0, "ring depth must divide the span");
+    static_assert(BM % (kRowsPerLoad * WAVES) == 0 && BM <= kThreads, "A tile must split evenly over the waves");
+    static_assert((kRowsPerLoad * WAVES) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
+    static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4);   // one stage: KT tile images, then their KT scale arrays
+    static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
+    static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && (PF == 1 || PF == 2), "stage = 1 or 2 k-tiles, 1 or 2 stages ahead");
+    static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
+    static_assert(NBUF * kStageU4 * 16 <= 160 * 1024, "LDS budget");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const GemmArgs p, const unsigned char *ws) {
+    using AT = typename Cfg::AT;
+    constexpr int KS = Cfg::KS, MB = Cfg::MB, NP = Cfg::NP, WAVES = Cfg::WAVES, D = Cfg::D, ACT = Cfg::ACT;
+    constexpr int KT = Cfg::KT, PF = Cfg::PF, NBUF = Cfg::NBUF;
+    constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;
+    constexpr int kRecDw = ScaleRec<kFmtMx, KS>::kDwords;
+    constexpr unsigned kOob = 0x80000000u;
+    constexpr int kFragU4 = ACT == 8 ? 2 : 1; // 16-byte units of one activation operand
+
+    // NBUF stages of [KT tile images][KT scale arrays]
+    __shared__ u32x4 smem[NBUF * Cfg::kStageU4];
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned m_l = lane & 31u, h = lane >> 5;
+
+    const unsigned ktiles = p.k / kTileK;
+    const unsigned nspans = ktiles / KS;
+    const unsigned ntiles = p.n / kTileN;
+    unsigned bn, bm;
+    tile_of_block(p.flags, bn, bm);
+    const unsigned nt0 = (bn * WAVES + wave) * (2 * NP);
+    const unsigned m0 = bm * Cfg::BM;
+    const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
+    const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
+    const unsigned kt_begin = sp_begin * KS;
+
+    f32x16 acc[MB][NP];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                acc[mb][np][v] = 0.f;
+
+    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)(2 * NP), ntiles - nt0) : 0u;
+    const unsigned w_row_bytes = ktiles * kTileBytes;
+    const unsigned s_row_bytes = p.k / 2;
+    const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
+    const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
+    const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
+    const __amdgpu_buffer_rsrc_t s_rsrc = make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
+    unsigned w_voff[2 * NP], s_voff[2 * NP];
+#pragma unroll
+    for (int nt = 0; nt < 2 * NP; ++nt) {
+        const unsigned rel = physical_tile(nt0 + nt, ntiles, p.act) - pt0;
+        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
+        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
+    }
+    // quantised activations and their scales (rows beyond M read as zeros: 0 * 2^-127)
+    const unsigned qa_row = p.k / 8 * ACT;
+    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * qa_row, rows * qa_row);
+    const __amdgpu_buffer_rsrc_t qs_rsrc =
+        make_rsrc(ws + (size_t)p.m * qa_row + (size_t)m0 * (p.k / 32), rows * (p.k / 32));
+
+    // direct-to-LDS staging.  Data: wave-load i of this wave covers rows RPL*(i*WAVES + wave) .. +RPL-1 (RPL = 8 / 16 rows of
+    // 128 / 64 bytes); lane l -> row + l / U, position l % U, which receives unit (l % U) ^ swz(row), U = 8 / 4 units per row,
+    // swz(row) = (row / 2) % 8 resp. (row / 4) % 4: the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte slots.
+    constexpr unsigned U = Cfg::kRowU4, RPL = Cfg::kRowsPerLoad;
+    const unsigned dma_row0 = wave * RPL + lane / U;
+    auto swz = [](unsigned row) -> unsigned { return ACT == 8 ? (row >> 1) & 7u : (row >> 2) & 3u; };
+    const unsigned dma_voff = dma_row0 * qa_row + (((lane % U) ^ swz(dma_row0)) * 16);
+    const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * (p.k / 32) : kOob;
+    auto dma_stage = [&](unsigned kt, unsigned buf) { // k-tiles kt .. kt + KT - 1 -> stage `buf`
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            u32x4 *const data = smem + buf * Cfg::kStageU4 + t * Cfg::kDataU4;
+#pragma unroll
+            for (int i = 0; i < Cfg::kDataLoads; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * WAVES + wave) * 64), 16,
+                                                         dma_voff, i * (RPL * WAVES) * qa_row + (kt + t) * (16 * ACT), 0, 0);
+            u32x4 *const sc = smem + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, (kt + t) * 4, 0, 0);
+        }
+#else
+        (void)kt, (void)buf;
+#endif
+    };
+    // fragment of (m32-block mb, operand q = P1 / P2): row 32 mb + m_l; FP8: units 4q + 2h, 4q + 2h + 1; FP4: unit 2q + h
+    struct Frags {
+        u32x4 d[MB][kFragU4];
+        int s[MB];
+    };
+    const unsigned my_swz = swz(m_l); // (32 mb is a multiple of every swizzle period)
+    auto read_frags = [&](const u32x4 *a_cur, const unsigned char *sc_bytes, int q, Frags &f) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const unsigned row = mb * 32 + m_l;
+#pragma unroll
+            for (int e = 0; e < kFragU4; ++e) {
+                const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
+                f.d[mb][e] = a_cur[row * U + (unit ^ my_swz)];
+            }
+            f.s[mb] = (int)sc_bytes[row * 4 + 2 * q + h]; // the block this lane's k belongs to: 2 q + h
+        }
+    };
+
+    // --- prologue: stage 0 (and 1 when two are kept ahead), scale records, the W ring
+    const unsigned kt_end = sp_end * KS;
+    dma_stage(kt_begin, 0);
+    if constexpr (PF == 2) {
+        if (kt_begin + KT < kt_end)
+            dma_stage(kt_begin + KT, 1);
+    }
+    ScaleRec<kFmtMx, KS> rec[NP][2], rec_next[NP][2];
+    auto load_recs = [&](ScaleRec<kFmtMx, KS> (*dst)[2], unsigned sp) {
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            const ScaleRec<kFmtMx, KS> x = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[2 * np], sp * 64 * kRecBytes);
+            const ScaleRec<kFmtMx, KS> y = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[2 * np + 1], sp * 64 * kRecBytes);
+#pragma unroll
+            for (int d = 0; d < kRecDw; ++d)
+                merge_tiles(x.d[d], y.d[d], dst[np][0].d[d], dst[np][1].d[d]);
+        }
+    };
+    load_recs(rec, sp_begin);
+    u32x4 wring[D][2 * NP];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int nt = 0; nt < 2 * NP; ++nt)
+            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxDefault);
+    __syncthreads(); // (drains everything once: stage 0 is complete and visible)
+
+    unsigned cur_buf = 0; // stage index of the current k-tiles, rotates with period NBUF (wave-uniform)
+    auto span_body = [&](const unsigned sp, auto last_c) {
+        constexpr bool kLast = decltype(last_c)::value;
+        const unsigned kt0 = sp * KS;
+        if constexpr (!kLast)
+            load_recs(rec_next, sp + 1);
+        static_for<0, KS / KT>([&](auto s_c) {
+            constexpr int S = decltype(s_c)::value, T0 = S * KT; // stage S of the span: k-tiles T0 .. T0 + KT - 1
+            constexpr bool kNextStage = !kLast || (T0 + KT < KS);
+            const unsigned kt = kt0 + T0;
+            const u32x4 *const stage = smem + cur_buf * Cfg::kStageU4;
+            const unsigned char *const stage_sc = reinterpret_cast<const unsigned char *>(stage + KT * Cfg::kDataU4);
+            // request the stage PF ahead: everybody left that LDS stage at the barrier that ended the previous stage
+            if constexpr (PF == 1) {
+                if constexpr (kNextStage)
+                    dma_stage(kt + KT, cur_buf ^ 1u);
+            } else {
+                // always issued (beyond the K slice the loads are out of the descriptor's range: zeros into a stage nobody
+                // reads), so the wait below is one constant and there is no branch around the MFMA stream
+                dma_stage(kt + 2 * KT, cur_buf == 0 ? 2u : cur_buf - 1);
+            }
+            Frags fr[2];
+            read_frags(stage, stage_sc, 0, fr[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            int refills = 0; // W loads issued in this stage (compile-time after unrolling)
+            static_for<0, KT>([&](auto t_c) {
+                constexpr int TI = decltype(t_c)::value, T = T0 + TI, SLOT = T % D;
+                constexpr bool kRefill = !kLast || (T + D < KS);
+                const u32x4 *const a_cur = stage + TI * Cfg::kDataU4;
+                const unsigned char *const sc_cur = stage_sc + TI * Cfg::kScaleU4 * 16;
+                // the pair's packed words, merged: the lane's 4 registers ARE the FP4 operand
+                i32x8 wop[NP][2];
+#pragma unroll
+                for (int np = 0; np < NP; ++np) {
+                    unsigned pw[2][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        merge_tiles(wring[SLOT][2 * np][j], wring[SLOT][2 * np + 1][j], pw[0][j], pw[1][j]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        wop[np][q] = i32x8{(int)pw[q][0], (int)pw[q][1], (int)pw[q][2], (int)pw[q][3], 0, 0, 0, 0};
+                }
+                static_for<0, 2>([&](auto q_c) {
+                    constexpr int q = decltype(q_c)::value, gi = 2 * TI + q; // group index inside the stage
+                    // fragments of the next group (next operand, or the next tile of the stage) while this group's MFMAs run
+                    if constexpr (gi + 1 < 2 * KT) {
+                        constexpr int nti = (gi + 1) / 2, nq = (gi + 1) % 2;
+                        read_frags(stage + nti * Cfg::kDataU4, stage_sc + nti * Cfg::kScaleU4 * 16, nq, fr[(gi + 1) & 1]);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) {
+                        i32x8 aop;
+                        if constexpr (ACT == 8) {
+                            const u32x4 lo = fr[gi & 1].d[mb][0], hi = fr[gi & 1].d[mb][kFragU4 - 1];
+                            aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                        } else {
+                            const u32x4 lo = fr[gi & 1].d[mb][0];
+                            aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], 0, 0, 0, 0};
+                        }
+#pragma unroll
+                        for (int np = 0; np < NP; ++np)
+                            acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, ACT == 8 ? 0 : 4 /* B = FP8 e4m3 / FP4 */, T % 4,
+                                (int)rec[np][q].d[T / 4], 0, fr[gi & 1].s[mb]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (kRefill && PF == 1) {
+#pragma unroll
+                    for (int nt = 0; nt < 2 * NP; ++nt)
+                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
+                }
+                (void)a_cur, (void)sc_cur, (void)refills;
+            });
+            if constexpr (PF == 1) {
+                if constexpr (kNextStage)
+                    __syncthreads();
+                cur_buf ^= 1u;
+            } else {
+                // the next stage (requested a stage ago) must have landed; the one requested at the top of this stage stays in
+                // flight: "at most kStageLoads outstanding" retires everything older (issue order).  W refills come AFTER the wait
+                // so that the count stays exact.
+                if constexpr (kNextStage) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kStageLoads) : "memory");
+                    __builtin_amdgcn_s_barrier();
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, KT>([&](auto t_c) {
+                    constexpr int T = T0 + decltype(t_c)::value, SLOT = T % D;
+                    if constexpr (!kLast || (T + D < KS)) {
+#pragma unroll
+                        for (int nt = 0; nt < 2 * NP; ++nt)
+                            wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
+                    }
+                });
+                cur_buf = cur_buf == 2 ? 0u : cur_buf + 1;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (!kLast) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+                rec[np][0] = rec_next[np][0], rec[np][1] = rec_next[np][1];
+        }
+    };
+    for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+        span_body(sp, std::false_type{});
+    span_body(sp_end - 1, std::true_type{});
+
+    // every MFMA executes with all 64 lanes, before the lane-divergent stores (see pin_acc in gemm_native.cuh)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(acc[mb][np]));
+#endif
+        }
+
+    // --- epilogue: the 32x32 accumulator layout of gemm_wide.cuh
+    const unsigned m_base = m0 + m_l;
+    if (gridDim.z > 1) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned m = m_base + mb * 32;
+                    const unsigned nt = 2 * np + (u >> 1);
+                    const unsigned n = (nt0 + nt) * 16 + (u & 1) * 8 + 4 * h;
+                    if (m < p.m && nt < valid_nt)
+                        *reinterpret_cast<f32x4 *>(p.workspace + ((size_t)blockIdx.z * p.m + m) * p.n + n) =
+                            f32x4{acc[mb][np][4 * u], acc[mb][np][4 * u + 1], acc[mb][np][4 * u + 2], acc[mb][np][4 * u + 3]};
+                }
+        return;
+    }
+    const float gs = *p.gs;
+    if (p.act) {
+        const unsigned n_half = p.n >> 1;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned m = m_base + mb * 32;
+                    const unsigned n = ((nt0 + 2 * np) >> 1) * 16 + u * 8 + 4 * h;
+                    const f32x16 &a = acc[mb][np];
+                    if (m < p.m && (unsigned)(2 * np + 1) < valid_nt)
+                        *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * n_half + n) * 2) = finish4_silu_mul<AT>(
+                            f32x4{a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]},
+                            f32x4{a[8 + 4 * u], a[8 + 4 * u + 1], a[8 + 4 * u + 2], a[8 + 4 * u + 3]}, gs, p.bias, n, n_half);
+                }
+        return;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int np = 0; np < NP; ++np)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned m = m_base + mb * 32;
+                const unsigned nt = 2 * np + (u >> 1);
+                const unsigned n = (nt0 + nt) * 16 + (u & 1) * 8 + 4 * h;
+                if (m < p.m && nt < valid_nt) {
+                    const f32x4 v = f32x4{acc[mb][np][4 * u], acc[mb][np][4 * u + 1], acc[mb][np][4 * u + 2], acc[mb][np][4 * u + 3]};
+                    *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
+                }
+            }
+}
+
+} // namespace petit_amd

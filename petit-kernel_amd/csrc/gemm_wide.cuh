@@ -269,15 +269,14 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
             const u32x4 *const a_cur = smem + cur_buf * Cfg::kBufU4;
             u32x4 *const a_pf = smem + pf_buf * Cfg::kBufU4;
             // the tile PF steps ahead: everybody left that buffer at the barrier that ended the previous step
-            bool pf_issued = false;
             if constexpr (PETIT_ABLATE & 1) {
             } else if constexpr (PF == 1) {
                 if constexpr (kNext)
                     dma_a_tile(a_pf, kt + 1);
             } else {
-                pf_issued = kt + 2 < kt_end;
-                if (pf_issued)
-                    dma_a_tile(a_pf, kt + 2);
+                // always issued (beyond K the loads are out of the descriptor's range: zeros into a buffer nobody reads), so the
+                // wait at the end of the step is one constant and no branch splits the MFMA stream
+                dma_a_tile(a_pf, kt + 2);
             }
             u32x4 fr[2][MB];
             read_frags(a_cur, 0, fr[0]);
@@ -325,10 +324,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
                 // Raw barrier: __syncthreads() would make hipcc drain the LDS-DMA queue (vmcnt(0)).
                 if constexpr (kNext) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                    if (pf_issued)
-                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kDmaLoads) : "memory");
-                    else
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kDmaLoads) : "memory");
                     __builtin_amdgcn_s_barrier();
 #endif
                 }

@@ -46,7 +46,7 @@ namespace petit_amd {
 
 enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
 enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u };
-enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u };
+enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u, kMfmaFp4 = 6u, kMfmaFp4ActFp16 = 6u | 8u };
 
 struct StreamShape {
     int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel
@@ -60,12 +60,17 @@ constexpr int kNativeAm = -2;
 // the 32x32x16-MFMA large-M kernel (gemm_wide.cuh): code 12; fields read tile_m = MB (m32-blocks), bits 52-55 = n-tiles
 // per wave (2 NP), warp_partition_n = WAVES
 constexpr int kWideAm = -3;
+// the native-FP4 kernels on the 32x32x64 block-scaled MFMA (gemm_native32.cuh): code 13; fields as kWideAm; pa = 1: activations
+// quantised to MXFP8 (mfma_type 2), pa = 2: to MXFP4 (mfma_type 6: FP4 x FP4); opt-in, never a default
+constexpr int kNative32Am = -4;
+constexpr bool is_native_am(int am) { return am == kNativeAm || am == kNative32Am; }
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
 // per-span block floating point (Bf16Bfp in gemm_stream.cuh); codes 5 / 6 / 7
 constexpr int kBfpAm = 100;
 constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {
     return am == kNativeAm ? 9u
+           : am == kNative32Am ? 13u
            : am == kWideAm  ? 12u
            : am == kTiledAm ? 8u
            : am == 0        ? 0u

@@ -963,6 +963,64 @@ def quantize_act_mxfp8(a_f32: np.ndarray) -> np.ndarray:
     return (q * scale).reshape(m, k)
 
 
+E2M1_GRID = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
+
+
+def quantize_act_mxfp4(a_f32: np.ndarray) -> np.ndarray:
+    """CPU statement of quantize_act32_kernel<., 4> (csrc/gemm_native32.cuh): per 32-k block the OCP-MX scale
+    2^(E - 2), E the exponent of the block maximum (so the maximum lands in [4, 8)), elements rounded to e2m1
+    (round-to-nearest-even on the grid 0 .5 1 1.5 2 3 4 6, saturating at 6).  Returns the DEQUANTISED activations."""
+    m, k = a_f32.shape
+    blk = a_f32.reshape(m, k // 32, 32).astype(np.float64)
+    amax = np.abs(blk).max(axis=2)
+    ebits = (amax.astype(np.float32).view(np.uint32) >> 23) & 0xFF
+    sbyte = np.where(amax == 0, 127, np.clip(ebits.astype(np.int64) - 2, 1, 254))
+    scale = np.ldexp(1.0, sbyte - 127)[:, :, None]
+    x = np.abs(blk) / scale
+    # nearest grid point; ties go to the even mantissa (grid indices 0, 2, 4, 6 are the even ones)
+    idx = np.searchsorted(E2M1_GRID, x, side="left").clip(1, 7)
+    lo, hi = E2M1_GRID[idx - 1], E2M1_GRID[idx]
+    pick_hi = (x - lo > hi - x) | ((x - lo == hi - x) & (idx % 2 == 0))
+    q = np.where(x >= 6.0, 6.0, np.where(pick_hi, hi, lo))
+    return (np.sign(blk) * q * scale).reshape(m, k).astype(np.float32)
+
+
+@pytest.mark.parametrize("is_bf16", [True, False])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512)])
+def test_native_fp4_activations(pk, m, n, k, is_bf16):
+    """FP4 x FP4 (MXFP4 weights raw, activations quantised on the fly to MXFP4: the 10 PFLOP/s instruction).  Opt-in,
+    ids carry mfma_type 6.  (1) exact semantics: against the oracle run on the CPU-emulated MXFP4 activations the kernel
+    is within the usual 1e-2 bound (only f32 summation order and the final rounding differ).  (2) stated end-to-end
+    tolerance against the unquantised oracle: e2m1 carries up to 2^-2 relative error per element (plus saturation of
+    block maxima in (6, 8) scale units: 25 %), so |c - ref| <= 0.12 * sum|a||w| + 1e-2 and rms error <= 25 % of the
+    output rms on these random problems -- an accuracy class for experiments, never a default."""
+    a_bits, q, s, gs = random_problem("mx", m, n, k, 5151 + m + n + k, is_bf16)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.b_type = pk.DataType.mxfloat4_e2m1
+    pk.ops.enable_native_fp4(True)
+    try:
+        fp4 = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 32) & 7 == 6]
+        assert fp4 and all((sid >> 48) & 0xF == 13 for sid in fp4)
+        a_f32 = to_f32(a_bits, is_bf16)
+        a_q = quantize_act_mxfp4(a_f32)
+        dq = O.dequant_mxfp4(q, s)
+        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq, gs)       # (4 significant bits x power of two: exact in bf16)
+        _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)
+        sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
+        for sid in fp4:
+            for splitk in (1, 2):
+                sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sk), is_bf16).astype(np.float64)
+                err = np.abs(c - exact)[fin]
+                assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all(), f"{sk:#x} max {err.max()}"
+                assert (np.abs(c - full)[fin] <= 0.12 * sum_abs[fin] + 1e-2).all(), f"{sk:#x}"
+                assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 0.25 * np.sqrt(np.mean(full[fin] ** 2)), f"{sk:#x}"
+    finally:
+        pk.ops.enable_native_fp4(False)
+
+
 @pytest.mark.parametrize("is_bf16", [True, False])
 @pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512)])
 def test_native_mxfp4(pk, m, n, k, is_bf16):

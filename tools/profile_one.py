@@ -43,18 +43,21 @@ gs = torch.ones(1, device=dev)
 hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1 if a.fmt == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1,
                            _lib.CXX_DTYPE_BF16, 0)
 sid = _lib.PETIT_SOLUTION_AUTO if a.solution == "auto" else int(a.solution, 16)
+ws = None
 if a.native:
     _lib.lib.petit_enable_native_fp4(1)
-    ws = torch.empty(int(_lib.lib.petit_native_workspace_bytes(m, k)), dtype=torch.uint8, device=dev)
-    _lib.lib.petit_set_workspace(C.c_void_p(ws.data_ptr()), C.c_uint64(ws.numel()))
     cnt = C.c_uint(0)
     _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, None, C.byref(cnt))
     ids = (C.c_uint64 * cnt.value)()
     _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, ids, C.byref(cnt))
-    native = [i for i in ids if (i >> 32) & 7 == 2]
-    if a.solution == "auto":   # tile_m * n-tiles per wave: the 128 x 256 shape
+    native = [i for i in ids if (i >> 48) & 0xF in (9, 13)]
+    if a.solution == "auto":   # tile_m * n-tiles per wave: the largest tile
         sid = max(native, key=lambda i: (i & 0xFF) * ((i >> 52) & 0xF))
     print("native solution", hex(sid), _lib.describe_solution(sid))
+need = int(_lib.lib.petit_gemm_workspace_bytes(C.byref(hints), m, n, k, C.c_uint64(sid)))
+if need:
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    _lib.lib.petit_set_workspace(C.c_void_p(ws.data_ptr()), C.c_uint64(need))
 fn = _lib.lib.petit_gemm_fp4_fp16_grid if a.fmt == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid
 torch.cuda.synchronize()
 for i in range(a.iters):

@@ -34,7 +34,7 @@ from petit_kernel import _lib
 
 
 def is_native(sid: int) -> bool:
-    return (sid >> 48) & 0xF == 9
+    return (sid >> 48) & 0xF in (9, 13)
 
 
 def main():
