@@ -22,6 +22,10 @@ LIB = ROOT / "lib" / "libpetit_amd.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-fno-gpu-rdc", "-DNDEBUG"]
+# kernel arguments preloaded into SGPRs by the command processor (gemm_stream.cuh: scalar arguments, most urgent first);
+# $PETIT_AMD_NO_KERNARG_PRELOAD=1 builds without (A/B measurements)
+if not os.environ.get("PETIT_AMD_NO_KERNARG_PRELOAD"):
+    FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def sources():
@@ -62,9 +66,36 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
     return LIB
 
 
+TORCH_LIB = ROOT / "lib" / "libpetit_torch.so"
+
+
+def build_torch_binding(force: bool = False) -> Path | None:
+    """csrc/torch_binding.cpp -> lib/libpetit_torch.so with the host compiler (no device code); needs torch's headers.
+    Returns None (with a note on stderr) when torch is not importable: the ctypes layer does not need it."""
+    src = CSRC / "torch_binding.cpp"
+    hdr = ROOT.parent / "include" / "petit_amd.h"
+    if not force and TORCH_LIB.exists() and TORCH_LIB.stat().st_mtime > max(src.stat().st_mtime, hdr.stat().st_mtime, LIB.stat().st_mtime):
+        return TORCH_LIB
+    try:
+        import torch
+        from torch.utils import cpp_extension as ce
+    except Exception as exc:  # noqa: BLE001
+        sys.stderr.write(f"[build] torch binding skipped: {exc}\n")
+        return None
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include", str(src), "-o", str(TORCH_LIB),
+                                                      f"-L{LIB.parent}", "-lpetit_amd"]
+    cmd += [f"-L{p}" for p in ce.library_paths()] + ["-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+                                                      "-Wl,-rpath,$ORIGIN"]
+    subprocess.run(cmd, check=True)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("-j", type=int, default=None)
     a = ap.parse_args()
     print(build(a.force, a.j))
+    print(build_torch_binding(a.force))

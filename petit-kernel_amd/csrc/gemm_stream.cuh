@@ -77,8 +77,19 @@ struct StreamCfg {
     static_assert(!AT::kBfp || (AM > 0 && KS >= 4 && FMT == 0), "block-floating-point A: staged NVFP4 path only");
 };
 
+// Scalar kernel arguments, most urgent first (not one GemmArgs struct): with -mllvm -amdgpu-kernarg-preload-count the
+// command processor hands the leading ones to every wave in SGPRs at launch, so a wave computes its first W / scale / A
+// addresses without waiting for the s_load round trip of the kernarg segment -- the decode kernel is all prologue
+// (every wave issues its whole share of loads at once), and that round trip sits in front of all of them.
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *arg_w, const void *arg_s, const void *arg_a,
+                                                                    unsigned arg_k, unsigned arg_n, unsigned arg_m,
+                                                                    unsigned arg_spw, unsigned arg_act, void *arg_c,
+                                                                    const float *arg_gs, const void *arg_bias,
+                                                                    float *arg_workspace) {
+    GemmArgs p;
+    p.c = arg_c, p.a = arg_a, p.w = arg_w, p.s = arg_s, p.gs = arg_gs, p.bias = arg_bias, p.act = arg_act;
+    p.workspace = arg_workspace, p.m = arg_m, p.n = arg_n, p.k = arg_k, p.spans_per_wave = arg_spw, p.flags = 0;
     using AT = typename Cfg::AT;
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT;
     constexpr int WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, AM = Cfg::AM, ABL = Cfg::ABL, PA = Cfg::PA;

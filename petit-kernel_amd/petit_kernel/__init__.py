@@ -12,8 +12,12 @@ import enum
 
 import torch
 
-from . import offline, ops
+from . import compiled, offline, ops
 from .ops import PetitSolutionHints
+
+# operator layer: the compiled torch.library binding when it is built and loads (csrc/torch_binding.cpp), else the
+# ctypes layer; both are thin shims over the same C ABI (there is no other compute path)
+_impl = compiled if compiled.available() else ops
 
 
 class DataType(enum.Enum):
@@ -28,20 +32,20 @@ class DataType(enum.Enum):
 
 
 def repack_nvfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
-    return ops.repack_nvfp4(qw, size_n, size_k)
+    return _impl.repack_nvfp4(qw, size_n, size_k)
 
 
 def process_nvfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
-    return ops.process_nvfp4_scales(scales, size_n, size_k)
+    return _impl.process_nvfp4_scales(scales, size_n, size_k)
 
 
 def repack_mxfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
     # weight packing is format-independent, as in the reference (:27-28)
-    return ops.repack_nvfp4(qw, size_n, size_k)
+    return _impl.repack_nvfp4(qw, size_n, size_k)
 
 
 def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
-    return ops.process_mxfp4_scales(scales, size_n, size_k)
+    return _impl.process_mxfp4_scales(scales, size_n, size_k)
 
 
 def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
@@ -50,13 +54,13 @@ def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scal
     # `bias` / `activation` are extensions (keyword-only, default None = the reference's behaviour):
     #   bias       [size_n] of a.dtype, added before the single rounding to 16 bit
     #   activation "silu_mul": returns [size_m, size_n/2] = silu(y[:, :n/2]) * y[:, n/2:]  (gate_up of a gated MLP)
-    return ops.mul_nvfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
+    return _impl.mul_nvfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def mul_mxfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
                   size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None,
                   activation: str = None) -> torch.Tensor:
-    return ops.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
+    return _impl.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def get_fp4_solutions(size_m: int, size_n: int, size_k: int, a_type, c_type) -> list:

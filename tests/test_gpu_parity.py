@@ -532,6 +532,42 @@ def test_nv_typed_solution_ids_work_with_mxfp4(pk, is_bf16):
     assert ran >= len(ids) // 2
 
 
+def test_compiled_and_ctypes_bindings_agree(pk):
+    """The compiled torch.library operator layer (csrc/torch_binding.cpp -> torch.ops.petit_kernel.*, the counterpart of
+    the reference's ATen extension lib/pybind/fp4.cc) and the ctypes layer are two shims over one C ABI: every op must
+    return bit-identical tensors through both, including the fused epilogues and a kernel that needs per-call scratch."""
+    from petit_kernel import compiled, ops
+    assert compiled.available(), compiled.why_unavailable()
+    assert pk._impl is compiled
+    for kind, is_bf16, m, n, k in [("nv", True, 3, 96, 1024), ("mx", True, 17, 64, 2048), ("nv", False, 130, 128, 1024), ("mx", False, 5, 64, 512)]:
+        dtype = torch.bfloat16 if is_bf16 else torch.float16
+        a, q, s, gs = random_problem(kind, m, n, k, 9100 + m, is_bf16)
+        ad, qd = from_bits(a, dtype).to(DEV), torch.from_numpy(q).to(DEV).view(torch.int32)
+        gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+        bias = torch.randn(n, device=DEV).to(dtype)
+        b1, b2 = compiled.repack_nvfp4(qd, n, k), ops.repack_nvfp4(qd, n, k)
+        assert torch.equal(b1, b2)
+        if kind == "nv":
+            sd = torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn)
+            s1, s2 = compiled.process_nvfp4_scales(sd, n, k), ops.process_nvfp4_scales(sd, n, k)
+            mul1, mul2 = compiled.mul_nvfp4_a16, ops.mul_nvfp4_a16
+        else:
+            sd = torch.from_numpy(s).to(DEV)
+            s1, s2 = compiled.process_mxfp4_scales(sd, n, k), ops.process_mxfp4_scales(sd, n, k)
+            mul1, mul2 = compiled.mul_mxfp4_a16, ops.mul_mxfp4_a16
+        assert torch.equal(s1.view(torch.uint8), s2.view(torch.uint8))
+        h = pk.PetitSolutionHints()
+        h.a_type = h.c_type = dtype
+        h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+        split = next(x for x in pk.ops.get_fp4_solutions(h, m, n, k) if (x >> 48) & 0xF == 0)
+        split = (split & ~(0xF << 60)) | (2 << 60)
+        for sid, kw in [(-1, {}), (-1, {"bias": bias}), (-1, {"activation": "silu_mul"}), (split, {})]:
+            c1, c2 = mul1(ad, b1, s1, gsd, m, n, k, sid, **kw), mul2(ad, b1, s1, gsd, m, n, k, sid, **kw)
+            assert c1.shape == c2.shape and torch.equal(c1.view(torch.int16), c2.view(torch.int16)), (kind, sid, kw)
+        check_gemm(bits(mul1(ad, b1, s1, gsd, m, n, k, -1)), oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16,
+                   oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+
+
 def test_offline_repack_matches_device(pk):
     """petit_kernel.offline (CPU, checkpoint-side tooling) == the device repack, bit for bit, and the GEMM
     accepts the CPU-packed tensors."""

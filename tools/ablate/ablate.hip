@@ -9,7 +9,8 @@ template <class AT, int MT, int NT, int WN, int WK, int D, int AM, int ABL> stat
     dim3 grid((ntiles + per_wg - 1) / per_wg, (a.m + 16 * MT - 1) / (16 * MT), 1);
     GemmArgs b = a;
     b.spans_per_wave = (a.k / 1024 + WK - 1) / WK;
-    hipLaunchKernelGGL(gemm_stream_kernel<Cfg>, grid, dim3(Cfg::kThreads), 0, st, b);
+    hipLaunchKernelGGL(gemm_stream_kernel<Cfg>, grid, dim3(Cfg::kThreads), 0, st, b.w, b.s, b.a, b.k, b.n, b.m, b.spans_per_wave,
+                       b.act, b.c, b.gs, b.bias, b.workspace);
 }
 
 // variant: (AT,MT,NT,WN,WK,D,AM) 0 = bfp (1,1,1,8,8,1) [bench default]  1 = bf16 (1,1,1,8,8,1)  2 = bf16 (1,2,1,4,4,16)  3 = bf16 (1,2,1,8,4,0)
