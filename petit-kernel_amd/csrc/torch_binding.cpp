@@ -9,8 +9,8 @@
 //
 // Built by petit-kernel_amd/build.py with the host compiler (no device code here) into lib/libpetit_torch.so.
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h> // (torch-ROCm devices are "cuda" devices: the masquerading forms)
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
 #include "../../include/petit_amd.h"
@@ -20,7 +20,7 @@ namespace {
 constexpr int64_t kLayoutN = 16, kLayoutM = 128, kPack = 8; // fp4.cc:17-19
 constexpr int kCxxFp4 = 3, kCxxFp16 = 4, kCxxBf16 = 5, kCxxMxFp4 = 7; // quantization/types.h:4-13
 
-void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
 at::Tensor repack_nvfp4(const at::Tensor &b_q_weight, int64_t size_n, int64_t size_k) {
     TORCH_CHECK(size_k % kLayoutM == 0, "size_k = ", size_k, " is not divisible by tile_k_size = ", kLayoutM);
@@ -31,7 +31,7 @@ at::Tensor repack_nvfp4(const at::Tensor &b_q_weight, int64_t size_n, int64_t si
     TORCH_CHECK(b_q_weight.is_cuda(), "b_q_weight is not on GPU");
     TORCH_CHECK(b_q_weight.is_contiguous(), "b_q_weight is not contiguous");
     TORCH_CHECK(b_q_weight.scalar_type() == at::kInt, "b_q_weight type is not kInt");
-    const c10::hip::HIPGuard guard(b_q_weight.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(b_q_weight.device());
     at::Tensor out = at::empty({size_n / kLayoutN, size_k * kLayoutN / kPack}, b_q_weight.options());
     const int rc = petit_repack_nvfp4_weights((unsigned *)out.data_ptr(), (const unsigned *)b_q_weight.data_ptr(), (unsigned)size_k,
                                               (unsigned)size_n, stream_of(out));
@@ -48,7 +48,7 @@ at::Tensor process_scales(const at::Tensor &scales, int64_t size_n, int64_t size
     TORCH_CHECK(scales.size(0) == size_n, "scales.size(0) = ", scales.size(0), " is not size_n = ", size_n);
     TORCH_CHECK(scales.is_cuda(), "scales is not on GPU");
     TORCH_CHECK(scales.is_contiguous(), "scales is not contiguous");
-    const c10::hip::HIPGuard guard(scales.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(scales.device());
     at::Tensor out;
     int rc;
     if (mx) {
@@ -95,7 +95,7 @@ at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::
         TORCH_CHECK(bias->is_cuda() && bias->device() == A.device() && bias->scalar_type() == A.scalar_type() && bias->is_contiguous() &&
                         bias->numel() == size_n,
                     "bias must be a contiguous [size_n] tensor of A's dtype on A's device");
-    const c10::hip::HIPGuard guard(A.device());
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(A.device());
     at::Tensor c = at::empty({size_m, activation ? size_n / 2 : size_n}, A.options());
     const int a_type = A.scalar_type() == at::kBFloat16 ? kCxxBf16 : kCxxFp16;
     const petit_solution_hints hints{a_type, mx ? kCxxMxFp4 : kCxxFp4, a_type, 0};
