@@ -174,6 +174,20 @@ int petit_repack_mxfp4_scales(unsigned *out_scales, const unsigned *scales,
                               unsigned in_chan, unsigned out_chan, void *stream);
 
 /*
+ * Dense dequantisation of PACKED weights, a debug / test aid:
+ *   out[n][k] = fp4(b[n][k]) * scale[n][k / g] * global_scale     row-major [n][k]
+ *   replaces DequantPetitFp4 / DequantPetitMxFp4  fp4/quantization_utils.cu:542-727 (the reference's test-only GPU
+ *            dequant kernels, quantization_utils_fp4_test.cc:103-133)
+ *   b, scales   packed tensors from petit_repack_*; b_type PETIT_DTYPE_FP4_E2M1 (e4m3 scales, g = 16) or
+ *               PETIT_DTYPE_MXFP4_E2M1 (e8m0, g = 32); n % 16 == 0, k % 256 == 0
+ *   out_type    PETIT_DTYPE_FP32 (exact for every code x scale), PETIT_DTYPE_BF16 or PETIT_DTYPE_FP16 (one RNE rounding)
+ * Uses the same hardware converts and scale decode as the GEMM kernels; the GEMM never calls it.
+ */
+#define PETIT_DTYPE_FP32 100 /* (not in the reference's enum: only this entry point takes it) */
+int petit_dequant_packed_weights(void *out, const unsigned *b, const unsigned *scales, float global_scale,
+                                 unsigned n, unsigned k, int b_type, int out_type, void *stream);
+
+/*
  * Offline twins of the three repack entry points for HOST memory: convert a checkpoint's native
  * NVFP4 / MXFP4 tensors into the packed layout on the CPU, so load-time GPU repack becomes
  * optional (the reference has no counterpart -- its repack exists only as

@@ -22,7 +22,7 @@ LIB = ROOT / "lib" / "libpetit_amd.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-fno-gpu-rdc", "-DNDEBUG"]
-# kernel arguments preloaded into SGPRs by the command processor (gemm_stream.cuh: scalar arguments, most urgent first);
+# kernel arguments preloaded into SGPRs by the command processor (gemm_stream.hpp: scalar arguments, most urgent first);
 # $PETIT_AMD_NO_KERNARG_PRELOAD=1 builds without (A/B measurements)
 if not os.environ.get("PETIT_AMD_NO_KERNARG_PRELOAD"):
     FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
@@ -33,7 +33,7 @@ def sources():
 
 
 def deps_mtime() -> float:
-    files = list(CSRC.glob("*.h")) + list(CSRC.glob("*.cuh")) + list(CSRC.glob("*.inc"))
+    files = list(CSRC.glob("*.h")) + list(CSRC.glob("*.hpp")) + list(CSRC.glob("*.inc"))
     files.append(ROOT.parent / "include" / "petit_amd.h")
     return max(f.stat().st_mtime for f in files)
 

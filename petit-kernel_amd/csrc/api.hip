@@ -16,8 +16,8 @@
 #include <cstring>
 
 #include "../../include/petit_amd.h"
-#include "gemm_native.cuh"
-#include "gemm_stream.cuh"
+#include "gemm_native.hpp"
+#include "gemm_stream.hpp"
 #include "hal.h"
 #include "layout.h"
 #include "petit_internal.h"
@@ -541,6 +541,14 @@ int petit_repack_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales,
     if ((!out_scales || !scales || out_scales == scales) && in_chan && out_chan)
         return kErrBadArgument;
     return repack_mxscales_host(out_scales, scales, in_chan, out_chan);
+}
+
+int petit_dequant_packed_weights(void *out, const unsigned *b, const unsigned *scales, float global_scale, unsigned n, unsigned k,
+                                 int b_type, int out_type, void *stream) {
+    if ((!out || !b || !scales) && n && k)
+        return kErrBadArgument;
+    const int kind = out_type == kDataTypeBf16 ? 1 : out_type == kDataTypeFp16 ? 2 : out_type == PETIT_DTYPE_FP32 ? 0 : -1;
+    return dequant_packed(out, b, scales, global_scale, n, k, b_type, kind, (hipStream_t)stream);
 }
 
 int petit_set_workspace(void *device_ptr, uint64_t bytes) {

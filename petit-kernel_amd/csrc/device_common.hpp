@@ -1,4 +1,4 @@
-// device_common.cuh -- what the three GEMM kernels (gemm_stream / gemm_tiled / gemm_native) share on the device:
+// device_common.hpp -- what the three GEMM kernels (gemm_stream / gemm_tiled / gemm_native) share on the device:
 // vector types, the activation-type tags, raw buffer loads, the E2M1 unpack (hardware converts), the MFMA
 // wrapper, the scale records of the packed layout, and the epilogue (global scale, optional bias / SiLU-mul, one
 // rounding).  Reference counterparts: quantization/dequant.cuh (unpack), rocm/amd_intrinsics.cuh:92-130 (buffer

@@ -1,4 +1,4 @@
-// gemm_native.cuh -- the native-FP4 path: MXFP4 weights fed RAW to the CDNA4 block-scaled MFMA
+// gemm_native.hpp -- the native-FP4 path: MXFP4 weights fed RAW to the CDNA4 block-scaled MFMA
 // (v_mfma_scale_f32_16x16x128_f8f6f4), activations quantised on the fly to MXFP8 (e4m3 elements,
 // one e8m0 scale per 32 k).  OPT-IN: quantising 16-bit activations to e4m3 costs ~2^-4 relative
 // per element, which breaks the 1e-2 parity bar of the dequant kernels, so
@@ -19,11 +19,11 @@
 //                 row / column, whichever lane holds the data bytes; opsel picks the byte of the VGPR.
 //
 // Two launches: quantize_act_kernel (A -> fp8 bytes in the operand's order + scales, into the
-// registered workspace) and gemm_native_kernel (tiled like gemm_tiled.cuh, A tile through LDS, written there by
+// registered workspace) and gemm_native_kernel (tiled like gemm_tiled.hpp, A tile through LDS, written there by
 // direct global -> LDS loads).
 #pragma once
 
-#include "gemm_tiled.cuh"
+#include "gemm_tiled.hpp"
 
 namespace petit_amd {
 
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const void *a, unsign
 }
 
 //   MT, NTW, WAVES, D as in TiledCfg.  The A tile (BM rows x 128 fp8 bytes) and its scale bytes (BM x 4) go
-//   global -> LDS directly (buffer_load ... lds, see gemm_tiled.cuh): rows are 8 un-padded 16-byte units with an
+//   global -> LDS directly (buffer_load ... lds, see gemm_tiled.hpp): rows are 8 un-padded 16-byte units with an
 //   XOR swizzle (unit u of row r at position u ^ ((r / 2) % 8): the 16 rows of a fragment read spread over all
 //   banks and the two units a lane needs stay one aligned 32-byte pair), scales are one dword per row.
 template <class AT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct NativeCfg {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     stagger_priority(p.flags);
     const unsigned nt0 = (bn * WAVES + wave) * NTW;
     const unsigned m0 = bm * Cfg::BM;
-    // K slice of this workgroup (gridDim.z > 1: see gemm_tiled.cuh)
+    // K slice of this workgroup (gridDim.z > 1: see gemm_tiled.hpp)
     const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
     const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
     const unsigned kt_begin = sp_begin * KS;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const Gem
     const unsigned w_row_bytes = ktiles * kTileBytes;
     const unsigned s_row_bytes = p.k / 2;
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
-    // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; device_common.cuh)
+    // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; device_common.hpp)
     const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
     const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
     const __amdgpu_buffer_rsrc_t w_rsrc =

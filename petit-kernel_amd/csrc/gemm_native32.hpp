@@ -1,15 +1,15 @@
-// gemm_native32.cuh -- the native-FP4 path on the 32x32x64 block-scaled MFMA, with FP8 or FP4 activations.
+// gemm_native32.hpp -- the native-FP4 path on the 32x32x64 block-scaled MFMA, with FP8 or FP4 activations.
 //
 // MXFP4 weights go RAW into v_mfma_scale_f32_32x32x64_f8f6f4 (zero unpack VALU); the 16-bit activations are quantised on
 // the fly by a first small kernel, either to MXFP8 (e4m3 elements + one e8m0 scale per 32 k: the instruction then runs at
 // the FP8 rate, 5 PFLOP/s dense) or to MXFP4 (e2m1 elements + e8m0 per 32 k: FP4 x FP4, the 10 PFLOP/s rate MI355X
-// quotes for its hardware FP4).  OPT-IN, like gemm_native.cuh: quantising activations is a different accuracy class
+// quotes for its hardware FP4).  OPT-IN, like gemm_native.hpp: quantising activations is a different accuracy class
 // (e4m3: 2^-4 relative per element, e2m1: 2^-2), never chosen by solution_id = -1; ids carry mfma_type 2 (FP8
 // activations) or 6 (FP4 activations).  Exact-semantics + stated-tolerance tests: tests/test_gpu_parity.py.
 //
-// What differs from gemm_native.cuh (16x16x128, FP8 only):
+// What differs from gemm_native.hpp (16x16x128, FP8 only):
 //  * 32x32x64 instruction: two neighbouring n-tiles are merged in registers with two lane swaps per packed word
-//    (merge_tiles, gemm_wide.cuh), P1 = the pair's 32 rows x k 0..63 of the tile, P2 = k 64..127 -- each IS the
+//    (merge_tiles, gemm_wide.hpp), P1 = the pair's 32 rows x k 0..63 of the tile, P2 = k 64..127 -- each IS the
 //    instruction's FP4 operand (lane (row, h): 32 consecutive k), and the merged span-record byte IS its per-lane
 //    E8M0 scale.  Half as many MFMAs per flop, half as many activation-fragment reads per flop.
 //  * a k-step is two groups (P1, P2); a group issues MB*NP MFMAs on MB*NP different accumulators while the fragments of
@@ -21,8 +21,8 @@
 //   scales                 the E8M0 byte of block b (k in [32b, 32b+32)) comes from lanes l/32 = b of the same row/column
 #pragma once
 
-#include "gemm_native.cuh"
-#include "gemm_wide.cuh"
+#include "gemm_native.hpp"
+#include "gemm_wide.hpp"
 
 namespace petit_amd {
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
         amax = fmaxf(amax, __shfl_xor(amax, 1));
         amax = fmaxf(amax, __shfl_xor(amax, 2));
         // E8M0 scale 2^(E - emax_elem) with E the exponent of the block maximum (OCP MX): emax_elem = 7 for e4m3 as
-        // gemm_native.cuh uses it (maximum lands in [128, 256) <= 448), 2 for e2m1 (maximum in [4, 8), above 6 saturates)
+        // gemm_native.hpp uses it (maximum lands in [128, 256) <= 448), 2 for e2m1 (maximum in [4, 8), above 6 saturates)
         constexpr unsigned kEmax = ACT == 8 ? 7u : 2u;
         const unsigned ebits = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
         unsigned sbyte = amax == 0.f ? 127u : (ebits > kEmax ? ebits - kEmax : 1u);
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
 //   KT   k-tiles per barrier ("stage"): the quantised activation tile is small (128 / 64 bytes per row and k-tile), and with
 //        zero unpack work a k-tile is only 2*MB*NP MFMAs, so one barrier per tile leaves the wave waiting on it.
 //   PF   stages requested ahead (NBUF = PF + 1 LDS stages): 1 = the next stage is requested at the top of a stage and waited
-//        for at its end; 2 = two ahead, in flight across the barrier (raw s_barrier + counted vmcnt, as gemm_wide.cuh PF = 2).
+//        for at its end; 2 = two ahead, in flight across the barrier (raw s_barrier + counted vmcnt, as gemm_wide.hpp PF = 2).
 //        Unlike the dequant kernels (power-limited) this kernel was latency-bound: a stage took the L2 round
 //        trip (~1900 cycles) for 512 cycles of MFMA work.
 template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1> struct Native32Cfg {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
         span_body(sp, std::false_type{});
     span_body(sp_end - 1, std::true_type{});
 
-    // every MFMA executes with all 64 lanes, before the lane-divergent stores (see pin_acc in gemm_native.cuh)
+    // every MFMA executes with all 64 lanes, before the lane-divergent stores (see pin_acc in gemm_native.hpp)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
 #endif
         }
 
-    // --- epilogue: the 32x32 accumulator layout of gemm_wide.cuh
+    // --- epilogue: the 32x32 accumulator layout of gemm_wide.hpp
     const unsigned m_base = m0 + m_l;
     if (gridDim.z > 1) {
 #pragma unroll

@@ -1,4 +1,4 @@
-// gemm_stream.cuh -- the weight-streaming FP4 GEMM for small M (decode regime).
+// gemm_stream.hpp -- the weight-streaming FP4 GEMM for small M (decode regime).
 //
 // Replaces GemmFp4Fp16KernelGrid and everything under it
 // (fp4/gemm_fp4_fp16_grid.cuh:441-498, fp4/warp_schedule_fp16.cuh:73-193,
@@ -27,7 +27,7 @@
 //    tile.
 #pragma once
 
-#include "device_common.cuh"
+#include "device_common.hpp"
 
 namespace petit_amd {
 

@@ -1,6 +1,6 @@
-// gemm_tiled.cuh -- the FP4 GEMM for large M (prefill regime, MFMA-bound).
+// gemm_tiled.hpp -- the FP4 GEMM for large M (prefill regime, MFMA-bound).
 //
-// Same contract, layout and unpack as gemm_stream.cuh; what changes is the reuse
+// Same contract, layout and unpack as gemm_stream.hpp; what changes is the reuse
 // structure.  At M >= ~64 every dequantised weight fragment must feed many MFMAs, and
 // every activation fragment must be shared by many weight tiles:
 //  * a workgroup owns a BM x BN tile of C (BM = 16*MT rows, BN = 16*NTW*WAVES columns)
@@ -19,7 +19,7 @@
 // ~200 VGPRs on purpose: accumulators for a 128 x 32 slab per wave).
 #pragma once
 
-#include "gemm_stream.cuh"
+#include "gemm_stream.hpp"
 
 namespace petit_amd {
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
 
     // a wave whose n-tiles all fall beyond N still helps staging A and hits the barriers
-    // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; device_common.cuh)
+    // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; device_common.hpp)
     const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
     const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
     const __amdgpu_buffer_rsrc_t w_rsrc =

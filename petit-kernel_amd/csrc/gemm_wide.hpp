@@ -1,6 +1,6 @@
-// gemm_wide.cuh -- the FP4 GEMM for large M on the 32x32x16 MFMA (prefill regime, MFMA-bound).
+// gemm_wide.hpp -- the FP4 GEMM for large M on the 32x32x16 MFMA (prefill regime, MFMA-bound).
 //
-// Same contract, packed layout and unpack as gemm_tiled.cuh; what changes is the matrix instruction and the
+// Same contract, packed layout and unpack as gemm_tiled.hpp; what changes is the matrix instruction and the
 // way its operands are kept fed:
 //  * v_mfma_f32_32x32x16_{bf16,f16}: one instruction does the work of two 16x16x32 ones, so a k-step issues half
 //    as many MFMAs and reads half as many operand registers per flop (the chip is power-limited under a full MFMA
@@ -22,12 +22,12 @@
 //    between two MFMAs on the same accumulator costs ~43 cycles (MI355X_MICROARCH.md), which is what held the
 //    16x16 kernel and the first 32x32 version at half the matrix rate.
 //  * A tile through LDS by direct global -> LDS loads, un-padded XOR-swizzled rows, one barrier per k-step; W never
-//    touches LDS; K split across workgroups (gridDim.z) as in gemm_tiled.cuh.
+//    touches LDS; K split across workgroups (gridDim.z) as in gemm_tiled.hpp.
 // Reference counterpart: fp4/gemm_fp4_fp16_grid.cuh:323-498 + warp_schedule_fp16.cuh (its 16x16x16 / 32x32x8 MFMA
 // schedule for CDNA2/3).
 #pragma once
 
-#include "gemm_tiled.cuh"
+#include "gemm_tiled.hpp"
 
 namespace petit_amd {
 
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
         w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
         s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
     }
-    // direct-to-LDS staging of the A tile, exactly as gemm_tiled.cuh: wave-load i of this wave covers rows
+    // direct-to-LDS staging of the A tile, exactly as gemm_tiled.hpp: wave-load i of this wave covers rows
     // 4*(i*WAVES + wave) .. +3; lane l -> row + l/16, position l%16, which receives unit (l%16) ^ (row%16)
     const unsigned dma_row0 = wave * 4 + (lane >> 4);
     const unsigned dma_voff = dma_row0 * p.k * 2 + (((lane & 15u) ^ (dma_row0 & 15u)) * 16);

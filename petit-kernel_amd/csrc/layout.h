@@ -48,7 +48,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define PETIT_HD __host__ __device__ inline
 #else
 #define PETIT_HD inline

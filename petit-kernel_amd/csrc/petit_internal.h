@@ -53,5 +53,7 @@ int repack_mxscales(void *out, const void *in, unsigned k, unsigned n, hipStream
 int repack_weights_host(void *out, const void *in, unsigned k, unsigned n);
 int repack_nvscales_host(void *out, const void *in, unsigned k, unsigned n);
 int repack_mxscales_host(void *out, const void *in, unsigned k, unsigned n);
+// dequant.hip: dense expansion of packed weights (debug aid); out_kind 0 f32, 1 bf16, 2 fp16
+int dequant_packed(void *out, const void *w, const void *s, float gs, unsigned n, unsigned k, int b_type, int out_kind, hipStream_t stream);
 
 } // namespace petit_amd

@@ -20,17 +20,17 @@
 //   bits 48-51  warp_partition    the reference's NK(0)/Cooperative(1) enum, never 1 in
 //                                 its shipped table; here: activation path,
 //                                 0 = direct L2 fragments, 1/2/3 = 1/2/4 rows staged
-//                                 through wave-private LDS (AM in gemm_stream.cuh),
+//                                 through wave-private LDS (AM in gemm_stream.hpp),
 //                                 10/11 = 8/16 rows staged the same way;
 //                                 5/6/7 = the same staged paths on the fp16 pipeline
 //                                 with block-floating-point activations (bf16 x NVFP4),
-//                                 9 = the native-FP4 kernel (gemm_native.cuh; mfma_type
+//                                 9 = the native-FP4 kernel (gemm_native.hpp; mfma_type
 //                                 nibble = 2, the reference's unused kMatmulMfmaTypeFp8,
 //                                 bit 35 set when the activations are fp16),
-//                                 8 = the tiled large-M kernel (gemm_tiled.cuh), whose
+//                                 8 = the tiled large-M kernel (gemm_tiled.hpp), whose
 //                                 fields read: tile_m = MT, warp_partition_n = WAVES,
 //                                 bits 52-55 = NTW, warp_partition_k = 1;
-//                                 12 = the 32x32x16-MFMA large-M kernel (gemm_wide.cuh):
+//                                 12 = the 32x32x16-MFMA large-M kernel (gemm_wide.hpp):
 //                                 tile_m = MB (m32-blocks), bits 52-55 = 2 NP
 //   bits 52-55  [was padding]     NT  n-tiles per wave
 //   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
@@ -54,18 +54,18 @@ struct StreamShape {
 };
 constexpr unsigned pa_code(int pa) { return pa == 8 ? 3u : pa == 4 ? 2u : pa == 2 ? 1u : 0u; }
 constexpr int kTiledAm = -1;
-// the native-FP4 kernels (gemm_native.cuh): MXFP4 weights straight into the block-scaled MFMA,
+// the native-FP4 kernels (gemm_native.hpp): MXFP4 weights straight into the block-scaled MFMA,
 // activations quantised to MXFP8; opt-in, never a default
 constexpr int kNativeAm = -2;
-// the 32x32x16-MFMA large-M kernel (gemm_wide.cuh): code 12; fields read tile_m = MB (m32-blocks), bits 52-55 = n-tiles
+// the 32x32x16-MFMA large-M kernel (gemm_wide.hpp): code 12; fields read tile_m = MB (m32-blocks), bits 52-55 = n-tiles
 // per wave (2 NP), warp_partition_n = WAVES
 constexpr int kWideAm = -3;
-// the native-FP4 kernels on the 32x32x64 block-scaled MFMA (gemm_native32.cuh): code 13; fields as kWideAm; pa = 1: activations
+// the native-FP4 kernels on the 32x32x64 block-scaled MFMA (gemm_native32.hpp): code 13; fields as kWideAm; pa = 1: activations
 // quantised to MXFP8 (mfma_type 2), pa = 2: to MXFP4 (mfma_type 6: FP4 x FP4); opt-in, never a default
 constexpr int kNative32Am = -4;
 constexpr bool is_native_am(int am) { return am == kNativeAm || am == kNative32Am; }
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
-// per-span block floating point (Bf16Bfp in gemm_stream.cuh); codes 5 / 6 / 7
+// per-span block floating point (Bf16Bfp in gemm_stream.hpp); codes 5 / 6 / 7
 constexpr int kBfpAm = 100;
 constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {
@@ -95,7 +95,7 @@ using LaunchFn = int (*)(const GemmArgs &, unsigned splitk, hipStream_t);
 struct SolutionEntry {
     StreamShape shape;
     int a_type; // kDataTypeBf16 / kDataTypeFp16
-    int fmt;    // kFmtNv / kFmtMx (gemm_stream.cuh)
+    int fmt;    // kFmtNv / kFmtMx (gemm_stream.hpp)
     LaunchFn launch;
 };
 

@@ -24,6 +24,7 @@ CXX_DTYPE_FP4_E2M1 = 3
 CXX_DTYPE_FP16 = 4
 CXX_DTYPE_BF16 = 5
 CXX_DTYPE_MXFP4_E2M1 = 7
+PETIT_DTYPE_FP32 = 100   # petit_dequant_packed_weights only
 
 
 class SolutionHints(C.Structure):
@@ -61,6 +62,7 @@ _SIGNATURES = {
     "petit_repack_nvfp4_weights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
     "petit_repack_nvfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
     "petit_repack_mxfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_dequant_packed_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
     "petit_set_workspace": (C.c_int, [C.c_void_p, C.c_uint64]),
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
     "petit_enable_native_fp4": (C.c_int, [C.c_int]),

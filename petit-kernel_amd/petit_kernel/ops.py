@@ -277,6 +277,24 @@ def workspace_bytes(hints: PetitSolutionHints, size_m: int, size_n: int, size_k:
     return int(_lib.lib.petit_gemm_workspace_bytes(C.byref(ch), size_m, size_n, size_k, C.c_uint64(sid)))
 
 
+def dequant_packed(B: torch.Tensor, s: torch.Tensor, size_n: int, size_k: int, kind: str = "nvfp4", dtype=torch.float32,
+                   global_scale: float = 1.0) -> torch.Tensor:
+    """Dense [size_n, size_k] expansion of PACKED weights (from repack_nvfp4 / process_*_scales): a debug aid, the
+    counterpart of the reference's test-only DequantPetitFp4 kernels (quantization_utils.cu:542-727)."""
+    _check(kind in ("nvfp4", "mxfp4"), "kind must be 'nvfp4' or 'mxfp4'")
+    _check(B.is_cuda and s.is_cuda and B.is_contiguous() and s.is_contiguous(), "packed tensors must be contiguous GPU tensors")
+    _check(B.numel() * B.element_size() == size_n * size_k // 2, "B does not hold size_n * size_k packed 4-bit weights")
+    out_type = {torch.float32: _lib.PETIT_DTYPE_FP32, torch.bfloat16: _lib.CXX_DTYPE_BF16, torch.float16: _lib.CXX_DTYPE_FP16}.get(dtype)
+    _check(out_type is not None, "dtype must be float32, bfloat16 or float16")
+    out = torch.empty((size_n, size_k), dtype=dtype, device=B.device)
+    with torch.cuda.device(B.device):
+        rc = _lib.lib.petit_dequant_packed_weights(_ptr(out), _ptr(B), _ptr(s), float(global_scale), size_n, size_k,
+                                                   _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1,
+                                                   out_type, _stream(B))
+    _raise_on(rc, "dequant_packed")
+    return out
+
+
 _workspace_keepalive = {}
 
 

@@ -111,6 +111,32 @@ def test_repack_bit_exact(pk, n, k):
     assert torch.equal(b, b2)
 
 
+@pytest.mark.parametrize("kind", ["nv", "mx"])
+def test_dense_dequant_debug_op(pk, golden_dir, kind):
+    """petit_dequant_packed_weights (the reference keeps DequantPetitFp4 / DequantPetitMxFp4 for the same purpose,
+    quantization_utils.cu:542-727): packed weights + packed scales -> dense f32, BIT EXACT against the oracle's
+    dequant on random data and on the exhaustive code x scale tables; bf16 / fp16 outputs are one RNE rounding of it."""
+    n, k = 96 if kind == "nv" else 64, 1024
+    _, q, s, _ = random_problem(kind, 1, n, k, 606, True)
+    if kind == "nv":
+        s = ((np.arange(n)[:, None] * 7 + np.arange(k // 16)[None, :]) % 126 + 1).astype(np.uint8)     # every positive e4m3 scale
+    else:
+        s = ((np.arange(n)[:, None] * 29 + np.arange(k // 32)[None, :]) % 237 + 1).astype(np.uint8)    # e8m0 1..237
+    qd = torch.from_numpy(q).to(DEV).view(torch.int32)
+    if kind == "nv":
+        b, sp = pk.repack_nvfp4(qd, n, k), pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+        want = O.dequant_nvfp4(q, s)
+    else:
+        b, sp = pk.repack_mxfp4(qd, n, k), pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+        want = O.dequant_mxfp4(q, s)
+    got = pk.ops.dequant_packed(b, sp, n, k, "nvfp4" if kind == "nv" else "mxfp4")
+    assert got.dtype == torch.float32 and np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    g16 = pk.ops.dequant_packed(b, sp, n, k, "nvfp4" if kind == "nv" else "mxfp4", torch.bfloat16)
+    assert np.array_equal(bits(g16), O.f32_to_bf16_bits(want))                      # exact: <= 5 significant bits
+    scaled = pk.ops.dequant_packed(b, sp, n, k, "nvfp4" if kind == "nv" else "mxfp4", torch.float32, 0.75)
+    assert np.array_equal(scaled.cpu().numpy(), want * np.float32(0.75))
+
+
 # --- exhaustive dequant truth tables through the GEMM, bit exact ----------------------
 
 @pytest.mark.parametrize("is_bf16", [True, False])
@@ -672,7 +698,7 @@ def test_fused_silu_mul_epilogue(pk, kind, is_bf16, with_bias, m, n, k):
 
 # --- adversarial activations: the kernels must not depend on the activations' dynamic range ---------------
 
-SPAN = 1024   # k per span at KS = 8: the block-floating-point unit of the Bf16Bfp kernels (csrc/gemm_stream.cuh)
+SPAN = 1024   # k per span at KS = 8: the block-floating-point unit of the Bf16Bfp kernels (csrc/gemm_stream.hpp)
 
 
 def adversarial_activations(m, k, q, is_bf16, seed, profile):
@@ -986,7 +1012,7 @@ def test_m512_full_size_tiled_and_native(pk, kind, shape):
 # --- the native-FP4 path (opt-in): exact semantics + its own stated tolerance ---------------------
 
 def quantize_act_mxfp8(a_f32: np.ndarray) -> np.ndarray:
-    """CPU statement of quantize_act_kernel (csrc/gemm_native.cuh): per 32-k block, E8M0 scale
+    """CPU statement of quantize_act_kernel (csrc/gemm_native.hpp): per 32-k block, E8M0 scale
     2^(E-7) with E the exponent of the block maximum, elements rounded to e4m3 (RNE).  Returns the
     DEQUANTISED activations (exactly representable in bf16: 4 significant bits x power of two)."""
     m, k = a_f32.shape
@@ -1003,7 +1029,7 @@ E2M1_GRID = np.array([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0])
 
 
 def quantize_act_mxfp4(a_f32: np.ndarray) -> np.ndarray:
-    """CPU statement of quantize_act32_kernel<., 4> (csrc/gemm_native32.cuh): per 32-k block the OCP-MX scale
+    """CPU statement of quantize_act32_kernel<., 4> (csrc/gemm_native32.hpp): per 32-k block the OCP-MX scale
     2^(E - 2), E the exponent of the block maximum (so the maximum lands in [4, 8)), elements rounded to e2m1
     (round-to-nearest-even on the grid 0 .5 1 1.5 2 3 4 6, saturating at 6).  Returns the DEQUANTISED activations."""
     m, k = a_f32.shape

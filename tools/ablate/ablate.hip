@@ -1,6 +1,6 @@
 // ablate.hip -- measurement-only build of the streaming kernel with pieces removed
 // (StreamCfg::ABL), to find out where the time of a launch goes.  Not shipped.
-#include "../../petit-kernel_amd/csrc/gemm_stream.cuh"
+#include "../../petit-kernel_amd/csrc/gemm_stream.hpp"
 using namespace petit_amd;
 
 template <class AT, int MT, int NT, int WN, int WK, int D, int AM, int ABL> static void launch(const GemmArgs &a, hipStream_t st) {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ablate_wide.sh -- builds ablation variants of the large-M 32x32 kernel (PETIT_ABLATE bits, gemm_wide.cuh) as
+# tools/ablate_wide.sh -- builds ablation variants of the large-M 32x32 kernel (PETIT_ABLATE bits, gemm_wide.hpp) as
 # separate libraries under tools/ablate/wide/ (bf16 x NVFP4 TU only; the other objects are the shipped ones).
 # Run on the GPU box: for each lib, PETIT_AMD_LIB=<lib> python tools/tune.py --no-check --kinds 12 ...
 R=$(cd "$(dirname "$0")/.." && pwd)

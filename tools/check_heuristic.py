@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/check_heuristic.py -- how good is the heuristic of csrc/api.hip where the arch table has no row?
 
-For every (dtype, shape, M) of the committed sweeps (profiles/r01_tune_*.json) ask the library for its pick with the
+For every (dtype, shape, M) of the committed sweeps (profiles/r01_sweeps.csv.gz) ask the library for its pick with the
 table disabled ($PETIT_AMD_NO_TUNED=1, no GPU needed) and look that solution up in the sweep's timings: prints the
 slowdown of the heuristic pick against the best measured solution.  Shapes outside the table get this quality."""
 import ctypes as C
@@ -15,25 +15,30 @@ os.environ["PETIT_AMD_NO_TUNED"] = "1"
 sys.path.insert(0, str(ROOT / "petit-kernel_amd"))
 from petit_kernel import _lib  # noqa: E402
 
+import csv
+
 worst, rows = [], 0
-for f in sorted((ROOT / "profiles").glob("r01_tune_*.json")):
-    if "native" in f.name or "vs_dense" in f.name:
-        continue
-    d = json.loads(f.read_text())
-    at = _lib.CXX_DTYPE_BF16 if d["dtype"] == "bf16" else _lib.CXX_DTYPE_FP16
-    bt = _lib.CXX_DTYPE_FP4_E2M1 if d["fmt"] == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
-    hints = _lib.SolutionHints(at, bt, at, 0)
-    for e in d["results"]:
-        ok = {int(r["solution"], 16): r["us_median"] for r in e["results"] if "us_median" in r}
-        if not ok:
+cells = {}   # (dtype, fmt, shape, n, k, m) -> {solution: us}
+import gzip
+for f in sorted((ROOT / "profiles").glob("r*_sweeps.csv.gz")):
+    if not f.name.startswith("r01"):
+        continue  # the heuristic was fitted on the r01 sweeps; later rounds only add kernels the arch table selects
+    for r in csv.DictReader(gzip.open(f, "rt")):
+        if r["fmt"] == "dense16" or "native" in r.get("sweep", "") or "vs_dense" in r.get("sweep", ""):
             continue
-        pick = _lib.lib.petit_gemm_default_solution(C.byref(hints), e["m"], e["n"], e["k"])
-        best = min(ok.values())
-        rows += 1
-        if pick in ok:
-            worst.append((ok[pick] / best, f"{d['dtype']}x{d['fmt']}", e["shape"], e["m"], _lib.describe_solution(pick).split("  (")[0]))
-        else:
-            worst.append((float("nan"), f"{d['dtype']}x{d['fmt']}", e["shape"], e["m"], "not timed: " + _lib.describe_solution(pick).split("  (")[0]))
+        key = (r["dtype"], r["fmt"], r["shape"], int(r["n"]), int(r["k"]), int(r["m"]))
+        cells.setdefault(key, {})[int(r["solution"], 16)] = float(r["us_median"])
+for (dtype, fmt, shape, n, k, m), ok in sorted(cells.items()):
+    at = _lib.CXX_DTYPE_BF16 if dtype == "bf16" else _lib.CXX_DTYPE_FP16
+    bt = _lib.CXX_DTYPE_FP4_E2M1 if fmt == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
+    hints = _lib.SolutionHints(at, bt, at, 0)
+    pick = _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k)
+    best = min(ok.values())
+    rows += 1
+    if pick in ok:
+        worst.append((ok[pick] / best, f"{dtype}x{fmt}", shape, m, _lib.describe_solution(pick).split("  (")[0]))
+    else:
+        worst.append((float("nan"), f"{dtype}x{fmt}", shape, m, "not timed: " + _lib.describe_solution(pick).split("  (")[0]))
 timed = sorted(w for w in worst if w[0] == w[0])
 print(f"{rows} cases, {len(timed)} heuristic picks found in the sweeps")
 import statistics

@@ -2,7 +2,7 @@
 """tools/check_mfma_exec.py -- static check: no MFMA may execute under a lane-divergent EXEC mask.
 
 MFMA reads its A/B operands from ALL 64 lanes; when the compiler sinks one into a divergent region
-(hipcc 7.2 does that to the block-scaled builtin, see gemm_native.cuh::pin_acc) the masked lanes'
+(hipcc 7.2 does that to the block-scaled builtin, see gemm_native.hpp::pin_acc) the masked lanes'
 rows are garbage.  Compiles every GEMM translation unit to gfx950 assembly and scans each kernel
 for a v_mfma between an EXEC modification and its restore.  Takes a few minutes (no GPU needed).
 """

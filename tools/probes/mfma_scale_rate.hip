@@ -18,7 +18,7 @@ template <int KIND> __global__ __launch_bounds__(256) void k(float *out, int ite
     f32x4 acc[8];
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int it = 0; it < iters; ++it) {
-        if constexpr (KIND == 0) {        // A fp4, B fp8: what gemm_native.cuh issues
+        if constexpr (KIND == 0) {        // A fp4, B fp8: what gemm_native.hpp issues
 #define S(i) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4" : "+v"(acc[i]) : "v"(a4), "v"(b8), "v"(s));
             LOOP8(S)
 #undef S
