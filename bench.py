@@ -393,17 +393,23 @@ def main() -> None:
         }
         print(f"[bench] headline {ms_per_step * 1e3:.3f} us/step", file=sys.stderr, flush=True)
         if world == 1:
+            # eager host cost per call of the two operator layers, on a TINY problem (M=1, N=256, K=1024: a ~2 us kernel), so
+            # that the host -- not the GPU -- is what the loop waits for (under graph replay, above, the host is out of the loop)
+            from petit_kernel import compiled, ops
+            tn, tk = 256, 1024
+            tq = torch.randint(0, 256, (tn, tk // 2), dtype=torch.uint8, device=dev)
+            tb = ops.repack_nvfp4(tq.view(torch.int32), tn, tk)
+            ts = ops.process_nvfp4_scales((torch.rand((tn, tk // 16), device=dev) * 3.5 + 0.25).to(torch.float8_e4m3fn), tn, tk)
+            ta = torch.randn((1, tk), device=dev).bfloat16()
             with torch.cuda.stream(stream):
-                line["host_us_per_call"] = {"ctypes": host_overhead(step)}
-                try:
-                    from petit_kernel import compiled
-                    if compiled.available():
-                        def cstep(i):
-                            b, sp = packed[i % copies]
-                            return compiled.mul_nvfp4_a16(a_d, b, sp, gs_d, M, N, K, -1)
-                        line["host_us_per_call"]["compiled_torch_library_op"] = host_overhead(cstep)
-                except Exception as exc:  # noqa: BLE001
-                    line["host_us_per_call"]["compiled_torch_library_op"] = f"unavailable: {exc}"
+                line["host_us_per_call"] = {"problem": f"M=1 N={tn} K={tk} bf16 x nvfp4, solution_id=-1, eager, one stream",
+                                            "ctypes": host_overhead(lambda i: ops.mul_nvfp4_a16(ta, tb, ts, gs_d, 1, tn, tk, -1))}
+                if compiled.available():
+                    line["host_us_per_call"]["compiled_torch_library_op"] = host_overhead(
+                        lambda i: compiled.mul_nvfp4_a16(ta, tb, ts, gs_d, 1, tn, tk, -1))
+                else:
+                    line["host_us_per_call"]["compiled_torch_library_op"] = f"unavailable: {compiled.why_unavailable()}"
+                line["host_us_per_call"]["package_default"] = "compiled" if petit_kernel._impl is compiled else "ctypes"
         del packed
         torch.cuda.empty_cache()
         if world == 1 and not args.no_cells:
