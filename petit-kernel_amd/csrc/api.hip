@@ -140,7 +140,10 @@ double stream_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k
     const double rounds = (double)(((unsigned)wgs + num_cus - 1) / num_cus);
     return 2.0 + blocks * (double)n * (double)k * per_weight * rounds * num_cus / wgs;
 }
-double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus) {
+// `splitk` K slices across workgroups (1 = none): each slice walks K / splitk, the grid is splitk times larger, and the fp32
+// slabs cost a second launch plus one write and one read of splitk * m * n floats (fitted on the r02 sweeps: sq8192 M = 128
+// 128x128 x4 modelled 28.4 us / measured 28.8; down M = 128 128x128 x8 72.7 / 75.3).
+double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus, unsigned splitk = 1) {
     const StreamShape &s = e.shape;
     const int acc = s.mt * s.nt; // accumulator tiles per wave: 8 = 64x128 / 128x64, 16 = 64x256 / 128x128
     const bool split = e.a_type == kDataTypeFp16 && e.fmt == kFmtMx; // two MFMAs per fragment, two LDS images
@@ -157,13 +160,19 @@ double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k,
     }
     const unsigned per_wg = s.nt * s.wn;
     const double wgs = (double)((m + 16 * s.mt - 1) / (16 * s.mt)) * (double)((n / kTileN + per_wg - 1) / per_wg);
-    double rounds = wgs / (num_cus * resident);
+    double rounds = wgs * splitk / (num_cus * resident);
     if (rounds < 1.0)
         rounds = 1.0;
-    return 2.0 + (k / kTileK) * t1 * rounds;
+    const double reduce = splitk > 1 ? 1.5 + (double)splitk * m * n * 8.0 / 5e6 : 0.0;
+    return 2.0 + (double)(k / kTileK) / splitk * t1 * rounds + reduce;
 }
 
-const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k, bool need_pairs = false) {
+// *splitk_out (when given): the heuristic may answer with a K split across workgroups for the tiled kernels (needs scratch:
+// callers without any pass nullptr and get the best kernel that needs none).
+const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k, bool need_pairs = false,
+                               unsigned *splitk_out = nullptr) {
+    if (splitk_out)
+        *splitk_out = 1;
     // Rules distilled from the MI355X sweeps (profiles/):
     //  * M <= 16: stage the activations through LDS (AM = smallest that holds M);
     //  * M <= 4: what saturates HBM is bytes in flight: as many resident waves as the grid allows, every wave with
@@ -183,8 +192,16 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
             if (!entry_fits(e, m, k) || is_native_am(s.am) || s.am == kWideAm || (need_pairs && !act_ok(e)))
                 continue; // (never the native-FP4 kernels: different accuracy class; the 32x32 kernels come from the arch table)
             double us;
+            unsigned sk = 1;
             if (s.am == kTiledAm) {
                 us = tiled_cost_us(e, m, n, k, arch.num_cus);
+                if (splitk_out && !need_pairs) { // K-heavy / narrow problems leave most CUs idle without a K split
+                    for (unsigned cand = 2; cand <= 8 && cand <= nspans; cand *= 2) {
+                        const double c = tiled_cost_us(e, m, n, k, arch.num_cus, cand);
+                        if (c < us)
+                            us = c, sk = cand;
+                    }
+                }
                 us -= 0.001 * s.d; // deeper ring on a tie
             } else {
                 if (s.am != 0 || s.wn != 1)
@@ -195,8 +212,11 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
                 if (nspans < (unsigned)s.wk)
                     us *= (double)s.wk / nspans; // idle K waves
             }
-            if (us < best_us)
+            if (us < best_us) {
                 best_us = us, best = &e;
+                if (splitk_out)
+                    *splitk_out = sk;
+            }
         }
         if (best)
             return best;
@@ -310,10 +330,8 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
                         (act && (!act_ok(*c.entry) || c.splitk != 1))))
             c.entry = nullptr;
     }
-    if (!c.entry) {
-        c.entry = heuristic(fam, m, n, k, act);
-        c.splitk = 1;
-    }
+    if (!c.entry)
+        c.entry = heuristic(fam, m, n, k, act, &c.splitk);
     slot = Slot{key0, key1, c};
     return c;
 }
@@ -400,10 +418,12 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         if (!ws) {
             if (!is_auto)
                 return kErrKernelShape; // explicit id that needs scratch nobody provided
-            splitk = 1;                 // AUTO without scratch: same kernel, no cross-workgroup K split
-            need = workspace_need(*entry, 1, m, n, k);
-            if (need)
-                return kErrKernelShape; // (unreachable: AUTO never picks a native kernel)
+            // AUTO without scratch: the best kernel that needs none (not the K-split pick minus its split: a tiled kernel
+            // chosen FOR its split leaves most of the chip idle without it)
+            entry = heuristic(fam, m, n, k, act);
+            splitk = 1;
+            if (!entry || workspace_need(*entry, 1, m, n, k))
+                return kErrKernelShape; // (unreachable: the heuristic never picks a native kernel)
         }
         args.workspace = (float *)ws;
     }
@@ -617,9 +637,9 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kOk;
     }
     if (s.am == kTiledAm) {
-        snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d  (wg tile %dx%d, %d threads)",
+        snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d splitk%u  (wg tile %dx%d, %d threads)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
-                 s.mt, s.nt, s.wn, s.d, 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
+                 s.mt, s.nt, s.wn, s.d, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
         return kOk;
     }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",
