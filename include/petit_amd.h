@@ -200,6 +200,19 @@ int petit_repack_nvfp4_scales_host(unsigned *out_scales, const unsigned *scales,
 int petit_repack_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan);
 
 /*
+ * Ingest of tensors that were already packed by the REFERENCE build (host memory, offline): a checkpoint repacked with
+ * the reference wheel's repack_nvfp4 / process_*_scales is converted to this build's layout without going back to the
+ * native tensors.  Input formats: RepackQWeightLayout64x32 + PetitFormat (quantization_utils.cu:20-87,183-253),
+ * RepackScaleLayout64x32 with the e4m3 -> "e5m3" byte transform (:89-162,255-304), RepackMxScaleLayout64x32 (:165-181).
+ * Same byte counts in and out, out of place only.  Weights: out_chan % 32 == 0, in_chan % 128 == 0; NV scales
+ * out_chan % 64 == 0 (the reference's kernel tiles 64 x 64, :755); MX scales out_chan % 32 == 0; in_chan % 256 == 0.
+ * The reference stores -0 as +0 (PetitFormat), which the conversion cannot and need not undo.
+ */
+int petit_convert_reference_weights_host(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan);
+int petit_convert_reference_nvfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan);
+int petit_convert_reference_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan);
+
+/*
  * Scratch memory ("workspace").  The reference API has no workspace argument (SURVEY.md section 8b "Ownership"); two
  * kinds of kernels here need device scratch: those that split K across workgroups (fp32 partial slabs, summed in a
  * fixed order by a second pass: deterministic, no float atomics) and the native-FP4 kernels (quantised activations).

@@ -563,6 +563,22 @@ int petit_repack_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales,
     return repack_mxscales_host(out_scales, scales, in_chan, out_chan);
 }
 
+int petit_convert_reference_weights_host(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan) {
+    if ((!output || !input || output == input) && in_chan && out_chan)
+        return kErrBadArgument;
+    return convert_reference_weights_host(output, input, in_chan, out_chan);
+}
+int petit_convert_reference_nvfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan) {
+    if ((!out_scales || !scales || out_scales == scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return convert_reference_nvscales_host(out_scales, scales, in_chan, out_chan);
+}
+int petit_convert_reference_mxfp4_scales_host(unsigned *out_scales, const unsigned *scales, unsigned in_chan, unsigned out_chan) {
+    if ((!out_scales || !scales || out_scales == scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return convert_reference_mxscales_host(out_scales, scales, in_chan, out_chan);
+}
+
 int petit_dequant_packed_weights(void *out, const unsigned *b, const unsigned *scales, float global_scale, unsigned n, unsigned k,
                                  int b_type, int out_type, void *stream) {
     if ((!out || !b || !scales) && n && k)

@@ -53,6 +53,10 @@ int repack_mxscales(void *out, const void *in, unsigned k, unsigned n, hipStream
 int repack_weights_host(void *out, const void *in, unsigned k, unsigned n);
 int repack_nvscales_host(void *out, const void *in, unsigned k, unsigned n);
 int repack_mxscales_host(void *out, const void *in, unsigned k, unsigned n);
+// reference-packed ("Petit" format of the reference wheel) -> this build's packed layout, host memory
+int convert_reference_weights_host(void *out, const void *in, unsigned k, unsigned n);
+int convert_reference_nvscales_host(void *out, const void *in, unsigned k, unsigned n);
+int convert_reference_mxscales_host(void *out, const void *in, unsigned k, unsigned n);
 // dequant.hip: dense expansion of packed weights (debug aid); out_kind 0 f32, 1 bf16, 2 fp16
 int dequant_packed(void *out, const void *w, const void *s, float gs, unsigned n, unsigned k, int b_type, int out_kind, hipStream_t stream);
 

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "petit_repack_nvfp4_weights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
     "petit_repack_nvfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
     "petit_repack_mxfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_convert_reference_weights_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_convert_reference_nvfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_convert_reference_mxfp4_scales_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
     "petit_dequant_packed_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
     "petit_set_workspace": (C.c_int, [C.c_void_p, C.c_uint64]),
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),

@@ -62,3 +62,39 @@ def process_mxfp4_scales_cpu(scales: torch.Tensor, size_n: int, size_k: int) -> 
     _raise_on(_lib.lib.petit_repack_mxfp4_scales_host(out.data_ptr(), scales.data_ptr(), size_k, size_n),
               "process_mxfp4_scales_cpu")
     return out
+
+
+# --- tensors already packed by the REFERENCE wheel -> this build's layout (include/petit_amd.h, petit_convert_reference_*) -----
+
+def from_reference_packed_weights(b_packed: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """int32 [N/16, 2K] as returned by the REFERENCE's repack_nvfp4 / repack_mxfp4 -> the same shape in this build's layout."""
+    _check(size_k % _LAYOUT_M == 0 and size_n % 32 == 0, "needs size_k % 128 == 0 and size_n % 32 == 0")
+    _check(b_packed.dtype == torch.int32 and b_packed.numel() * 4 == size_n * size_k // 2, "b_packed does not hold size_n * size_k 4-bit weights")
+    _cpu(b_packed, "b_packed")
+    out = torch.empty((size_n // _LAYOUT_N, size_k * _LAYOUT_N // _PACK), dtype=torch.int32)
+    _raise_on(_lib.lib.petit_convert_reference_weights_host(out.data_ptr(), b_packed.contiguous().data_ptr(), size_k, size_n),
+              "from_reference_packed_weights")
+    return out
+
+
+def from_reference_packed_nvfp4_scales(s_packed: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """[N, K/16] bytes as returned by the REFERENCE's process_nvfp4_scales ("e5m3" bytes in its layout) -> float8_e4m3fn
+    [N, K/16] in this build's layout."""
+    _check(size_k % (2 * _LAYOUT_M) == 0 and size_n % 64 == 0, "needs size_k % 256 == 0 and size_n % 64 == 0")
+    _check(s_packed.numel() * s_packed.element_size() == size_n * size_k // 16, "s_packed does not hold size_n * size_k / 16 scale bytes")
+    _cpu(s_packed, "s_packed")
+    out = torch.empty((size_n, size_k // 16), dtype=torch.uint8)
+    _raise_on(_lib.lib.petit_convert_reference_nvfp4_scales_host(out.data_ptr(), s_packed.contiguous().data_ptr(), size_k, size_n),
+              "from_reference_packed_nvfp4_scales")
+    return out.view(torch.float8_e4m3fn)
+
+
+def from_reference_packed_mxfp4_scales(s_packed: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """uint8 [N/32, K] as returned by the REFERENCE's process_mxfp4_scales -> the same shape in this build's layout."""
+    _check(size_k % (2 * _LAYOUT_M) == 0 and size_n % 32 == 0, "needs size_k % 256 == 0 and size_n % 32 == 0")
+    _check(s_packed.dtype == torch.uint8 and s_packed.numel() == size_n * size_k // 32, "s_packed does not hold size_n * size_k / 32 scale bytes")
+    _cpu(s_packed, "s_packed")
+    out = torch.empty((size_n // 32, size_k), dtype=torch.uint8)
+    _raise_on(_lib.lib.petit_convert_reference_mxfp4_scales_host(out.data_ptr(), s_packed.contiguous().data_ptr(), size_k, size_n),
+              "from_reference_packed_mxfp4_scales")
+    return out

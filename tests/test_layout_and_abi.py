@@ -327,6 +327,36 @@ def test_workspace_bytes_query():
     assert need(0x1234) == 0
 
 
+@pytest.mark.parametrize("n,k", [(64, 256), (128, 512), (192, 1024), (64, 2048)])
+def test_ingest_of_reference_packed_tensors(n, k):
+    """A checkpoint already repacked by the REFERENCE wheel converts to this build's layout on the host
+    (petit_convert_reference_*): the oracle's restatement of the reference's packed formats (PetitFormat nibble
+    re-encode + RepackQWeightLayout64x32, the e4m3 -> "e5m3" scale bytes, the MX scale layout) produces the input,
+    and the result must equal this build's own repack of the native tensors, byte for byte (modulo the sign of zero,
+    which the reference's format drops)."""
+    import petit_kernel
+    rng = np.random.default_rng(n + k)
+    q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+    q_nozero_sign = q.copy()                                   # the reference stores -0 as +0: compare on that form
+    lo, hi = q_nozero_sign & 0x0F, q_nozero_sign >> 4
+    lo[lo == 8] = 0
+    hi[hi == 8] = 0
+    q_nozero_sign = (lo | (hi << 4)).astype(np.uint8)
+    ref_w = O.petit_repack_weights(q.view(np.uint32).reshape(n, k // 8))
+    got_w = petit_kernel.offline.from_reference_packed_weights(torch.from_numpy(ref_w.view(np.int32)).reshape(n // 16, 2 * k), n, k)
+    want_w = petit_kernel.offline.repack_nvfp4_cpu(torch.from_numpy(q_nozero_sign).view(torch.int32), n, k)
+    assert torch.equal(got_w, want_w)
+    s = rng.integers(0, 0x7F, (n, k // 16), dtype=np.uint8)   # every non-negative, non-NaN e4m3 byte (incl. subnormals)
+    ref_s = O.petit_repack_nvscales(s, k)
+    got_s = petit_kernel.offline.from_reference_packed_nvfp4_scales(torch.from_numpy(ref_s).reshape(n, k // 16), n, k)
+    want_s = petit_kernel.offline.process_nvfp4_scales_cpu(torch.from_numpy(s).view(torch.float8_e4m3fn), n, k)
+    assert torch.equal(got_s.view(torch.uint8), want_s.view(torch.uint8))
+    mx = rng.integers(0, 256, (n, k // 32), dtype=np.uint8)
+    ref_mx = O.petit_repack_mxscales(mx, k)
+    got_mx = petit_kernel.offline.from_reference_packed_mxfp4_scales(torch.from_numpy(ref_mx).reshape(n // 32, k), n, k)
+    assert torch.equal(got_mx, petit_kernel.offline.process_mxfp4_scales_cpu(torch.from_numpy(mx), n, k))
+
+
 def test_heuristic_stays_close_to_the_measured_best():
     """Where the arch table has no row the heuristic decides: replayed (table disabled) against every case of the
     committed MI355X sweeps its median must stay within 1.03x of the best measured solution, 90 % of the cases within 1.2x, the worst

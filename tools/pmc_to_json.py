@@ -30,7 +30,7 @@ sq, _ = medians(ROOT / f"gpurun_out/pmc_sq_{tag}/p_counter_collection.csv")
 rd = 2 * fetch["FETCH_SIZE"] * 1024
 wr = write["WRITE_SIZE"] * 1024
 out = {
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE|SQ_* --output-format csv -- python3 bench.py --no-cpu-baseline --no-graph "
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE|SQ_* --output-format csv -- python3 bench.py --no-cpu-baseline --no-cells --no-graph "
                "--steps 200 --warmup 200 (separate passes, tools/collect_profiles.sh)",
     "kernel": "petit_amd::gemm_stream_kernel (bench.py default solution, M=1 N=K=8192 bf16 x nvfp4)",
     "FETCH_SIZE_KB_median": fetch["FETCH_SIZE"],
