@@ -218,6 +218,7 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cells", action="store_true", help="headline only (skip the M x shape table)")
+    ap.add_argument("--no-host-overhead", action="store_true", help="skip the eager host-cost measurement (profiling runs)")
     ap.add_argument("--cells-budget-s", type=float, default=150.0)
     ap.add_argument("--cells-child", default="", help=argparse.SUPPRESS)   # internal: run the cell table, append JSON lines to this file
     ap.add_argument("--rotate-mb", type=int, default=1280,
@@ -392,7 +393,7 @@ def main() -> None:
             },
         }
         print(f"[bench] headline {ms_per_step * 1e3:.3f} us/step", file=sys.stderr, flush=True)
-        if world == 1:
+        if world == 1 and not args.no_host_overhead:
             # eager host cost per call of the two operator layers, on a TINY problem (M=1, N=256, K=1024: a ~2 us kernel), so
             # that the host -- not the GPU -- is what the loop waits for (under graph replay, above, the host is out of the loop)
             from petit_kernel import compiled, ops

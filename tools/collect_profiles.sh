@@ -6,19 +6,18 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 python $R/bench.py > $R/gpurun_out/bench_${TAG}.json 2> $R/gpurun_out/bench_${TAG}.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -o bench -- python3 $R/bench.py --no-cpu-baseline --no-cells > $R/gpurun_out/prof_${TAG}.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_fetch_${TAG}.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_write_${TAG}.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_sq_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -o bench -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-host-overhead > $R/gpurun_out/prof_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-host-overhead --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_fetch_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-host-overhead --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_write_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/pmc_sq_${TAG} -o p -- python3 $R/bench.py --no-cpu-baseline --no-cells --no-host-overhead --no-graph --steps 200 --warmup 200 > $R/gpurun_out/pmc_sq_${TAG}.log 2>&1
 cd $R; cat gpurun_out/bench_${TAG}.json; head -3 gpurun_out/prof_${TAG}/bench_kernel_stats.csv | cut -c1-300
 # MFMA utilisation at M = 512 (BASELINE config 5): the default (tiled dequant) kernel and the native-FP4 kernel on gate_up
 cd /tmp
+# (native: the FP4 x FP4 32x32x64 kernel the sweeps rank first on gate_up, 128x256, 2 k-tiles per stage, 2 stages ahead)
 for v in "nv tiled" "mx native"; do
   set -- $v
-  EXTRA=""; [ "$2" = "native" ] && EXTRA="--native"
+  EXTRA=""; [ "$2" = "native" ] && EXTRA="--native --solution 144da41623301004"
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$2_${TAG} -o p -- python3 $R/tools/profile_one.py --m 512 --n 57344 --k 8192 --fmt $1 $EXTRA --iters 20 > $R/gpurun_out/pmc_mfma_$2_${TAG}.log 2>&1
 done
 cd $R
-python3 tools/pmc_to_json.py ${TAG} ${TAG} > gpurun_out/pmc_to_json_${TAG}.log 2>&1
-python3 tools/pmc_mfma_to_json.py ${TAG} >> gpurun_out/pmc_to_json_${TAG}.log 2>&1
-tail -5 gpurun_out/pmc_to_json_${TAG}.log
+# afterwards, in the repo (gpurun merges gpurun_out/ back): python3 tools/pmc_to_json.py ${TAG} ${TAG}; python3 tools/pmc_mfma_to_json.py ${TAG}
