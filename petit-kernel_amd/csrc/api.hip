@@ -344,8 +344,11 @@ const SolutionEntry *find_explicit(const Family &fam, uint64_t id) {
     id = (id & ~((uint64_t)0xf << 28)) | ((uint64_t)fam.elem_b << 28);
     const SolutionEntry *e = find_entry(fam, id);
     const unsigned am = (unsigned)(id >> 48) & 0xf;
+    // NVFP4-only kernel kinds named on the MXFP4 entry point: the plain staged kernel with the same geometry
     if (!e && fam.elem_b == kElemBMxFp4 && am >= 5 && am <= 7)
         e = find_entry(fam, (id & ~((uint64_t)0xf << 48)) | ((uint64_t)(am - 4) << 48));
+    if (!e && fam.elem_b == kElemBMxFp4 && (am == 4 || am == 14 || am == 15))
+        e = find_entry(fam, (id & ~((uint64_t)0xf << 48)) | ((uint64_t)(am == 4 ? 1 : am == 14 ? 2 : 3) << 48));
     return e;
 }
 
@@ -662,7 +665,9 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
              a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
              s.mt, s.nt, s.wn, s.wk, s.d, am_rows(s.am), solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
              64 * s.wn * s.wk);
-    if (s.am >= kBfpAm)
+    if (s.am >= kDecodeAm)
+        strncat(buf, " scale-after-mfma", len - strlen(buf) - 1);
+    else if (s.am >= kBfpAm)
         strncat(buf, " bfp16", len - strlen(buf) - 1);
     if (s.pa > 1) {
         char t[16];

@@ -3,4 +3,5 @@
 #define PETIT_TU_FMT kFmtNv
 #define PETIT_TU_TABLE solutions_nv_bf16
 #define PETIT_TU_BFP_AT Bf16Bfp
+#define PETIT_TU_DECODE
 #include "stream_tu.inc"

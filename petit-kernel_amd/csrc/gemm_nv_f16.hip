@@ -2,4 +2,5 @@
 #define PETIT_TU_AT Fp16
 #define PETIT_TU_FMT kFmtNv
 #define PETIT_TU_TABLE solutions_nv_f16
+#define PETIT_TU_DECODE
 #include "stream_tu.inc"

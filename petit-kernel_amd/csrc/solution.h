@@ -31,7 +31,10 @@
 //                                 fields read: tile_m = MT, warp_partition_n = WAVES,
 //                                 bits 52-55 = NTW, warp_partition_k = 1;
 //                                 12 = the 32x32x16-MFMA large-M kernel (gemm_wide.hpp):
-//                                 tile_m = MB (m32-blocks), bits 52-55 = 2 NP
+//                                 tile_m = MB (m32-blocks), bits 52-55 = 2 NP;
+//                                 13 = the 32x32x64 native-FP4 kernel (gemm_native32.hpp);
+//                                 4 / 14 / 15 = the NVFP4 decode kernel that scales after the
+//                                 MFMA (gemm_decode.hpp), 1 / 2 / 4 activation rows
 //   bits 52-55  [was padding]     NT  n-tiles per wave
 //   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
 //   bits 60-63  [was padding]     split-K across workgroups (gridDim.z), >= 1
@@ -67,7 +70,10 @@ constexpr bool is_native_am(int am) { return am == kNativeAm || am == kNative32A
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
 // per-span block floating point (Bf16Bfp in gemm_stream.hpp); codes 5 / 6 / 7
 constexpr int kBfpAm = 100;
-constexpr int am_rows(int am) { return am >= kBfpAm ? am - kBfpAm : am; }
+// am 201 / 202 / 204: the NVFP4 decode kernel with the group scale applied after the MFMA (gemm_decode.hpp), holding
+// 1 / 2 / 4 activation rows; codes 4 / 14 / 15
+constexpr int kDecodeAm = 200;
+constexpr int am_rows(int am) { return am >= kDecodeAm ? am - kDecodeAm : am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {
     return am == kNativeAm ? 9u
            : am == kNative32Am ? 13u
@@ -76,6 +82,7 @@ constexpr unsigned am_code(int am) {
            : am == 0        ? 0u
            : am == 8        ? 10u
            : am == 16       ? 11u
+           : am >= kDecodeAm ? (am == kDecodeAm + 1 ? 4u : am == kDecodeAm + 2 ? 14u : 15u)
                             : (am_rows(am) == 1 ? 1u : am_rows(am) == 2 ? 2u : 3u) + (am >= kBfpAm ? 4u : 0u);
 }
 
