@@ -387,7 +387,7 @@ def main() -> None:
                 "frac": per_gpu_gbs / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "petit_amd::gemm_stream_kernel",
+                "kernel": "petit_amd::gemm_decode_kernel" if (sid >> 48) & 0xF in (4, 14, 15) else "petit_amd::gemm_stream_kernel",
                 "bytes_per_launch": bytes_per_step,
                 "us_per_launch": ms_per_step * 1e3,
             },

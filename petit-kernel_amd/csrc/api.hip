@@ -250,6 +250,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         double score = 0.0;
         score -= 4.0 * (am_rows(s.am) != want_am);
         score += 0.5 * (s.am >= kBfpAm); // bf16 x NVFP4, M <= 4: the fp16 pipeline unpacks cheaper
+        score += 0.5 * (s.am >= kDecodeAm); // NVFP4, M <= 4: scale applied after the MFMA, cheaper still (gemm_decode.hpp)
         score -= 1.0 * (s.nt != want_nt);
         // wave count: under-filling costs more than over-filling
         score -= busy < target_waves ? 3.0 * (1.0 - busy / target_waves) : 0.25 * (busy / target_waves - 1.0);

@@ -277,7 +277,8 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256), (7, 96, 2048)])
+@pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256), (7, 96, 2048),
+                                   (3, 48, 512), (4, 80, 1536), (1, 48, 768), (2, 4128, 4096)])
 @pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
 def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
     """The counterpart of the reference's one-gtest-per-tile-shape list
@@ -772,6 +773,8 @@ def test_adversarial_activations_every_solution(pk, kind, is_bf16, m, profile):
     sols = pk.ops.get_fp4_solutions(h, m, n, k)
     if kind == "nv" and is_bf16 and m <= 4:
         assert any((sid >> 48) & 0xF in (5, 6, 7) for sid in sols), "the block-floating-point kernels must be in the list"
+    if kind == "nv" and m <= 4:
+        assert any((sid >> 48) & 0xF in (4, 14, 15) for sid in sols), "the scale-after-MFMA decode kernels must be in the list"
     for sid in [-1] + list(sols):
         c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid)
         try:
@@ -806,6 +809,42 @@ def test_nonfinite_activations(pk, m):
         fin = np.isfinite(ref)
         if fin.any():
             assert (np.abs(got - ref)[fin] <= np.maximum(1e-2, 1e-2 * np.abs(ref[fin]))).all(), f"{sid:#x}"
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+@pytest.mark.parametrize("is_bf16", [True, False])
+def test_decode_kernels_extreme_range(pk, m, is_bf16):
+    """The scale-after-MFMA decode kernels (csrc/gemm_decode.hpp, kinds 4 / 14 / 15) sum a * w4 per scale group BEFORE the
+    group scale is applied.  Activations near the top of the type's range times |w4| = 6 x 16 terms must not overflow
+    f32 where the pre-scaled form (e4m3 scales of 2^-9 .. 2^-7 here) stays finite: a handful of huge activations per row, random
+    signs, small scales and global scale.  Every decode kernel and the default choice against the oracle."""
+    n, k = 64, 8 * SPAN
+    rng = np.random.default_rng(99 + m)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    top = 2.0 ** 126 if is_bf16 else 32768.0
+    for row in range(m):
+        cols = rng.choice(k, 8, replace=False)
+        a[row, cols] = top * rng.choice([-1.0, 1.0], 8) * rng.uniform(0.5, 1.0, 8)
+        # a whole scale group of same-sign near-maximum values: 16 x 6 x 2^126 > f32 max without the kernel's 2^-7
+        g0 = 16 * int(rng.integers(0, k // 16))
+        a[row, g0:g0 + 16] = top * 0.9
+    a_bits = O.f32_to_bf16_bits(a) if is_bf16 else a.astype(np.float16).view(np.uint16)
+    q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+    sf = np.exp2(rng.integers(-9, -6, (n, k // 16))).astype(np.float32) * rng.choice([1.0, 1.25, 1.75], (n, k // 16)).astype(np.float32)
+    s = torch.from_numpy(sf).to(torch.float8_e4m3fn).view(torch.uint8).numpy()
+    gs = 2.0 ** -12 if is_bf16 else 2.0 ** -6
+    with np.errstate(over="ignore"):
+        ref = oracle_ref("nv", a_bits, is_bf16, q, s, gs)
+    assert np.isfinite(ref).all() and np.abs(ref).max() > (1e30 if is_bf16 else 1.0)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.b_type = pk.DataType.float4_e2m1
+    decode = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF in (4, 14, 15)]
+    assert decode
+    for sid in [-1] + decode:
+        got = to_f32(run_case(pk, "nv", a_bits, is_bf16, q, s, gs, m, n, k, sid), is_bf16)
+        assert np.isfinite(got).all(), f"{sid:#x}: spurious overflow"
+        assert (np.abs(got - ref) <= np.maximum(1e-2, 1e-2 * np.abs(ref))).all(), f"{sid:#x}"
 
 
 # --- BASELINE.json full sizes: oracle on the whole problem + size-independent properties --

@@ -15,9 +15,9 @@ ALG = 8192 * 8192 // 2 + 8192 * 8192 // 16 + 2 * 8192 + 2 * 8192 + 4
 
 
 def medians(path):
-    """Per-launch medians over the dispatches of the HEADLINE kernel: the gemm_stream instance with the largest grid (the
+    """Per-launch medians over the dispatches of the HEADLINE kernel: the gemm_decode / gemm_stream instance with the largest grid (the
     bench also launches small repack / warm-up kernels)."""
-    rows = [r for r in csv.DictReader(open(path)) if "gemm_stream_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "gemm_stream_kernel" in r["Kernel_Name"] or "gemm_decode_kernel" in r["Kernel_Name"]]
     if not rows:
         return {}, 0
     big = max(rows, key=lambda r: int(r.get("Grid_Size", 0) or 0))
@@ -37,7 +37,7 @@ wr = write["WRITE_SIZE"] * 1024
 out = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE|SQ_* --output-format csv -- python3 bench.py --no-cpu-baseline --no-cells --no-graph "
                "--steps 200 --warmup 200 (separate passes, tools/collect_profiles.sh)",
-    "kernel": "petit_amd::gemm_stream_kernel (bench.py default solution, M=1 N=K=8192 bf16 x nvfp4)",
+    "kernel": "petit_amd::gemm_decode_kernel (bench.py default solution, M=1 N=K=8192 bf16 x nvfp4)",
     "FETCH_SIZE_KB_median": fetch["FETCH_SIZE"],
     "WRITE_SIZE_KB_median": write["WRITE_SIZE"],
     "dispatches": n,
