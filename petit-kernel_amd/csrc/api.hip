@@ -242,8 +242,8 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         if (!entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
             continue;
         const StreamShape &s = e.shape;
-        if (s.mt != want_mt || s.am == kTiledAm || is_native_am(s.am) || s.am == kWideAm)
-            continue;
+        if (s.mt != want_mt || s.am == kTiledAm || is_native_am(s.am) || s.am == kWideAm || s.wm != 1)
+            continue; // (the shared-activation-tile kernels, wm = 2, come from the arch table only)
         const unsigned wgs = (ntiles + s.wn * s.nt - 1) / (s.wn * s.nt);
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
         const double busy = (double)wgs * s.wn * busy_wk;
@@ -666,6 +666,8 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
              a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
              s.mt, s.nt, s.wn, s.wk, s.d, am_rows(s.am), solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
              64 * s.wn * s.wk);
+    if (s.wm == 2)
+        strncat(buf, " shared-a", len - strlen(buf) - 1);
     if (s.am >= kDecodeAm)
         strncat(buf, " scale-after-mfma", len - strlen(buf) - 1);
     else if (s.am >= kBfpAm)

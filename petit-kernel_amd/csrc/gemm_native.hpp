@@ -110,13 +110,14 @@ template <class AT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> struct Nati
     static constexpr int kDataU4 = BM * 8;                   // one tile image
     static constexpr int kScaleU4 = kThreads / 4;            // one dword per thread (rows >= BM: junk zeros)
     static constexpr int kDataLoads = BM * 8 / 64 / WAVES;   // 1 KiB wave-loads per wave per tile
+    static constexpr int kMinWavesPerSimd = MT * NTW > 16 ? 1 : 2; // (64 x 320: 80 accumulator registers, one wave per SIMD)
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert((BM * 8) % (64 * WAVES) == 0 && BM <= kThreads, "A tile must split evenly over the waves");
     static_assert((8 * WAVES) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
 };
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads, 2) void gemm_native_kernel(const GemmArgs p, const unsigned char *ws) {
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_native_kernel(const GemmArgs p, const unsigned char *ws) {
     using AT = typename Cfg::AT;
     constexpr int KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
     constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;

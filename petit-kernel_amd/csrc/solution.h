@@ -14,7 +14,9 @@
 //                                 every gfx950 kernel dequantises exactly
 //   bits 28-31  element_b         1 NVFP4, 2 MXFP4          (MatmulElementB)
 //   bits 32-35  mfma_type         0 fp16, 1 bf16            (MatmulMfmaType)
-//   bits 36-39  warp_partition_m  1
+//   bits 36-39  warp_partition_m  1; 2 = the 5 <= M <= 16 kernel whose WN waves of a K part share one
+//                                 activation tile in LDS (gemm_mid.hpp; warp_partition = 10 / 11 as the
+//                                 staged streaming kernels: 8 / 16 rows)
 //   bits 40-43  warp_partition_n  WN
 //   bits 44-47  warp_partition_k  WK
 //   bits 48-51  warp_partition    the reference's NK(0)/Cooperative(1) enum, never 1 in
@@ -54,6 +56,7 @@ enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16
 struct StreamShape {
     int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel
     int pa = 1;                    // direct-path activation prefetch distance (1, 2, 4 or 8 tiles)
+    int wm = 1;                    // warp_partition_m nibble: 2 = the shared-activation-tile kernel (gemm_mid.hpp)
 };
 constexpr unsigned pa_code(int pa) { return pa == 8 ? 3u : pa == 4 ? 2u : pa == 2 ? 1u : 0u; }
 constexpr int kTiledAm = -1;
@@ -89,7 +92,7 @@ constexpr unsigned am_code(int am) {
 constexpr uint64_t make_solution_id(const StreamShape &s, unsigned elem_b, unsigned mfma, unsigned splitk) {
     return (uint64_t)(s.mt & 0xff) | ((uint64_t)((s.wn * s.nt) & 0xff) << 8) |
            ((uint64_t)(((2 * s.ks) & 0x1f) | (pa_code(s.pa) << 5)) << 16) | ((uint64_t)(kFeatGrid | kFeatHighPrecision) << 24) |
-           ((uint64_t)(elem_b & 0xf) << 28) | ((uint64_t)(mfma & 0xf) << 32) | ((uint64_t)1 << 36) |
+           ((uint64_t)(elem_b & 0xf) << 28) | ((uint64_t)(mfma & 0xf) << 32) | ((uint64_t)(s.wm & 0xf) << 36) |
            ((uint64_t)(s.wn & 0xf) << 40) | ((uint64_t)(s.wk & 0xf) << 44) | ((uint64_t)am_code(s.am) << 48) |
            ((uint64_t)(s.nt & 0xf) << 52) |
            ((uint64_t)(s.d & 0xf) << 56) | ((uint64_t)(splitk & 0xf) << 60);
