@@ -24,9 +24,20 @@
 #include "gemm_native.hpp"
 #include "gemm_wide.hpp"
 
+// measurement-only builds (tools/ablate_native32.sh): 1 = no activation DMA, 2 = no W refills, 4 = fragments read once,
+// 8 = no MFMAs (operands kept alive), 16 = no output stores.  0 in every shipped library.
+#ifndef PETIT_ABLATE_N32
+#define PETIT_ABLATE_N32 0
+#endif
+
 namespace petit_amd {
 
-// Workspace layout: qa[M][K * ACT / 8] bytes, then qs[M][K/32] E8M0 bytes.
+// Workspace layout, K-TILE MAJOR: qa[K/128][M][16 ACT] bytes, then qs[K/128][M][4] E8M0 bytes -- the activation tile of a
+// workgroup and k-tile (BM rows x 128 k) is ONE contiguous run, so every 1 KiB wave-load of the GEMM's direct-to-LDS staging
+// reads eight whole cache lines (with the row-major form qa[M][K ACT / 8] a wave-load touched 16 half lines 4 KiB apart, and
+// the activation DMA cost more than the weight stream: 8.9 vs 4.8 us of a 30.6 us launch at 8192^2, M = 512 --
+// tools/ablate_native32.sh).  Rows >= M of the last m-block read the next tile's rows (or zeros past the end): such rows
+// only feed output columns that are never stored.
 //   ACT = 8: per 128-k tile 128 bytes in the order [0-15][32-47][16-31][48-63][64-79][96-111][80-95][112-127] (16-k units),
 //            so that lane (m, h) finds its P1 operand at byte 32h and its P2 operand at byte 64 + 32h.
 //   ACT = 4: per 128-k tile 64 bytes, natural nibble order: P1 operand at byte 16h, P2 at 32 + 16h.
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
             const unsigned pos = (u16 & 4u) | ((u16 & 1u) << 1) | ((u16 >> 1) & 1u);
             uint2 o;
             o.x = (unsigned)q0, o.y = (unsigned)q1;
-            *reinterpret_cast<uint2 *>(qa + (size_t)row * row_bytes + kt * 128 + pos * 16 + half * 8) = o;
+            *reinterpret_cast<uint2 *>(qa + ((size_t)kt * m + row) * 128 + pos * 16 + half * 8) = o;
         } else {
             // hardware RNE conversion to e2m1 with saturation: dst nibbles = cvt(src / scale)
             const float scale = __builtin_bit_cast(float, sbyte << 23); // 2^(sbyte-127)
@@ -91,10 +102,10 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
             q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[2], v[3], scale, 1);
             q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[4], v[5], scale, 2);
             q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[6], v[7], scale, 3);
-            *reinterpret_cast<unsigned *>(qa + (size_t)row * row_bytes + kt * 64 + col16 * 4) = q;
+            *reinterpret_cast<unsigned *>(qa + ((size_t)kt * m + row) * 64 + col16 * 4) = q;
         }
         if ((c8 & 3) == 0)
-            qs[(size_t)row * (k / 32) + c8 / 4] = (unsigned char)sbyte;
+            qs[((size_t)kt * m + row) * 4 + (c8 / 4) % 4] = (unsigned char)sbyte;
     }
 }
 
@@ -105,20 +116,26 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
 //        for at its end; 2 = two ahead, in flight across the barrier (raw s_barrier + counted vmcnt, as gemm_wide.hpp PF = 2).
 //        Unlike the dequant kernels (power-limited) this kernel was latency-bound: a stage took the L2 round
 //        trip (~1900 cycles) for 512 cycles of MFMA work.
-template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1> struct Native32Cfg {
+//   WM   waves along M (1 or 2): the workgroup is WM x WAVES waves, every wave owns MB m32-blocks x NP n-pairs, the WM waves
+//        of a column stream the SAME weight tiles (the second request hits the CU's L1).  WM = 2 puts two waves on every
+//        SIMD for the same 128 x 128 workgroup tile: with one wave per SIMD the stage's DMA / LDS reads / W refills and its
+//        MFMAs were issued by the same in-order instruction stream and did not overlap (0.25 MFMA utilisation measured).
+template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1> struct Native32Cfg {
     using AT = AT_;
     static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, PF = PF_, NBUF = PF_ + 1;
-    static constexpr int kThreads = 64 * WAVES;
-    static constexpr int BM = 32 * MB;
+    static constexpr int WM = WM_, kWaves = WAVES * WM;
+    static constexpr int kThreads = 64 * kWaves;
+    static constexpr int BM = 32 * MB * WM;
     static constexpr int kRowU4 = ACT;                        // 16-byte units per LDS row: 128 B (FP8) / 64 B (FP4)
     static constexpr int kDataU4 = BM * kRowU4;               // one tile image
     static constexpr int kScaleU4 = (BM + 3) / 4 < kThreads / 4 ? kThreads / 4 : (BM + 3) / 4; // one dword per row (wave-loads of 64)
     static constexpr int kRowsPerLoad = 64 / kRowU4;          // rows one 1 KiB wave-load covers: 8 / 16
-    static constexpr int kDataLoads = BM / kRowsPerLoad / WAVES;
+    static constexpr int kDataLoads = BM / kRowsPerLoad / kWaves;
     static_assert(ACT == 8 || ACT == 4, "activations are quantised to MXFP8 or MXFP4");
     static_assert(KS % D == 0, "ring depth must divide the span");
-    static_assert(BM % (kRowsPerLoad * WAVES) == 0 && BM <= kThreads, "A tile must split evenly over the waves");
-    static_assert((kRowsPerLoad * WAVES) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
+    static_assert(WM == 1 || WM == 2, "one or two waves along M");
+    static_assert(BM % (kRowsPerLoad * kWaves) == 0 && BM <= kThreads, "A tile must split evenly over the waves");
+    static_assert((kRowsPerLoad * kWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
     static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4);   // one stage: KT tile images, then their KT scale arrays
     static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
     static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && (PF == 1 || PF == 2), "stage = 1 or 2 k-tiles, 1 or 2 stages ahead");
@@ -130,7 +147,7 @@ template <class Cfg>
 __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const GemmArgs p, const unsigned char *ws) {
     using AT = typename Cfg::AT;
     constexpr int KS = Cfg::KS, MB = Cfg::MB, NP = Cfg::NP, WAVES = Cfg::WAVES, D = Cfg::D, ACT = Cfg::ACT;
-    constexpr int KT = Cfg::KT, PF = Cfg::PF, NBUF = Cfg::NBUF;
+    constexpr int KT = Cfg::KT, PF = Cfg::PF, NBUF = Cfg::NBUF, WM = Cfg::WM, kWaves = Cfg::kWaves;
     constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;
     constexpr int kRecDw = ScaleRec<kFmtMx, KS>::kDwords;
     constexpr unsigned kOob = 0x80000000u;
@@ -142,6 +159,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wn = WM == 1 ? wave : wave % WAVES, wm = WM == 1 ? 0u : wave / WAVES; // (the WM waves of a column: wave, wave + WAVES)
     const unsigned m_l = lane & 31u, h = lane >> 5;
 
     const unsigned ktiles = p.k / kTileK;
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
     const unsigned ntiles = p.n / kTileN;
     unsigned bn, bm;
     tile_of_block(p.flags, bn, bm);
-    const unsigned nt0 = (bn * WAVES + wave) * (2 * NP);
+    const unsigned nt0 = (bn * WAVES + wn) * (2 * NP);
     const unsigned m0 = bm * Cfg::BM;
     const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
     const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
@@ -179,11 +197,13 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
         w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
         s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
     }
-    // quantised activations and their scales (rows beyond M read as zeros: 0 * 2^-127)
-    const unsigned qa_row = p.k / 8 * ACT;
-    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * qa_row, rows * qa_row);
-    const __amdgpu_buffer_rsrc_t qs_rsrc =
-        make_rsrc(ws + (size_t)p.m * qa_row + (size_t)m0 * (p.k / 32), rows * (p.k / 32));
+    // quantised activations and their scales, k-tile major (see the layout note above): tile kt of this m-block starts at
+    // (kt M + m0) rows of 16 ACT (data) / 4 (scales) bytes; the descriptors end with the data / scale region
+    constexpr unsigned kRowB = 16 * ACT;
+    const size_t qa_bytes = (size_t)p.m * (p.k / 8 * ACT), qs_bytes = (size_t)p.m * (p.k / 32);
+    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * kRowB, (unsigned)(qa_bytes - (size_t)m0 * kRowB));
+    const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + qa_bytes + (size_t)m0 * 4, (unsigned)(qs_bytes - (size_t)m0 * 4));
+    const unsigned qa_tile = p.m * kRowB, qs_tile = p.m * 4; // bytes from one k-tile to the next
 
     // direct-to-LDS staging.  Data: wave-load i of this wave covers rows RPL*(i*WAVES + wave) .. +RPL-1 (RPL = 8 / 16 rows of
     // 128 / 64 bytes); lane l -> row + l / U, position l % U, which receives unit (l % U) ^ swz(row), U = 8 / 4 units per row,
@@ -191,19 +211,19 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
     constexpr unsigned U = Cfg::kRowU4, RPL = Cfg::kRowsPerLoad;
     const unsigned dma_row0 = wave * RPL + lane / U;
     auto swz = [](unsigned row) -> unsigned { return ACT == 8 ? (row >> 1) & 7u : (row >> 2) & 3u; };
-    const unsigned dma_voff = dma_row0 * qa_row + (((lane % U) ^ swz(dma_row0)) * 16);
-    const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * (p.k / 32) : kOob;
+    const unsigned dma_voff = dma_row0 * kRowB + (((lane % U) ^ swz(dma_row0)) * 16);
+    const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * 4 : kOob;
     auto dma_stage = [&](unsigned kt, unsigned buf) { // k-tiles kt .. kt + KT - 1 -> stage `buf`
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !(PETIT_ABLATE_N32 & 1)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             u32x4 *const data = smem + buf * Cfg::kStageU4 + t * Cfg::kDataU4;
 #pragma unroll
             for (int i = 0; i < Cfg::kDataLoads; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * WAVES + wave) * 64), 16,
-                                                         dma_voff, i * (RPL * WAVES) * qa_row + (kt + t) * (16 * ACT), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * kWaves + wave) * 64), 16,
+                                                         dma_voff, i * (RPL * kWaves) * kRowB + (kt + t) * qa_tile, 0, 0);
             u32x4 *const sc = smem + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, (kt + t) * 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, (kt + t) * qs_tile, 0, 0);
         }
 #else
         (void)kt, (void)buf;
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
     auto read_frags = [&](const u32x4 *a_cur, const unsigned char *sc_bytes, int q, Frags &f) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            const unsigned row = mb * 32 + m_l;
+            const unsigned row = (wm * MB + mb) * 32 + m_l;
 #pragma unroll
             for (int e = 0; e < kFragU4; ++e) {
                 const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
@@ -300,29 +320,37 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
                 static_for<0, 2>([&](auto q_c) {
                     constexpr int q = decltype(q_c)::value, gi = 2 * TI + q; // group index inside the stage
                     // fragments of the next group (next operand, or the next tile of the stage) while this group's MFMAs run
-                    if constexpr (gi + 1 < 2 * KT) {
+                    if constexpr (gi + 1 < 2 * KT && !(PETIT_ABLATE_N32 & 4)) {
                         constexpr int nti = (gi + 1) / 2, nq = (gi + 1) % 2;
                         read_frags(stage + nti * Cfg::kDataU4, stage_sc + nti * Cfg::kScaleU4 * 16, nq, fr[(gi + 1) & 1]);
                     }
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb) {
                         i32x8 aop;
+                        constexpr int fi = (PETIT_ABLATE_N32 & 4) ? 0 : (gi & 1);
                         if constexpr (ACT == 8) {
-                            const u32x4 lo = fr[gi & 1].d[mb][0], hi = fr[gi & 1].d[mb][kFragU4 - 1];
+                            const u32x4 lo = fr[fi].d[mb][0], hi = fr[fi].d[mb][kFragU4 - 1];
                             aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
                         } else {
-                            const u32x4 lo = fr[gi & 1].d[mb][0];
+                            const u32x4 lo = fr[fi].d[mb][0];
                             aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], 0, 0, 0, 0};
                         }
 #pragma unroll
-                        for (int np = 0; np < NP; ++np)
-                            acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                                wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, ACT == 8 ? 0 : 4 /* B = FP8 e4m3 / FP4 */, T % 4,
-                                (int)rec[np][q].d[T / 4], 0, fr[gi & 1].s[mb]);
+                        for (int np = 0; np < NP; ++np) {
+                            if constexpr (PETIT_ABLATE_N32 & 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                                asm volatile("" ::"v"(wop[np][q]), "v"(aop), "v"(fr[fi].s[mb]), "v"(rec[np][q].d[T / 4]));
+#endif
+                            } else {
+                                acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                                    wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, ACT == 8 ? 0 : 4 /* B = FP8 e4m3 / FP4 */, T % 4,
+                                    (int)rec[np][q].d[T / 4], 0, fr[fi].s[mb]);
+                            }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                if constexpr (kRefill && PF == 1) {
+                if constexpr (kRefill && PF == 1 && !(PETIT_ABLATE_N32 & 2)) {
 #pragma unroll
                     for (int nt = 0; nt < 2 * NP; ++nt)
                         wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<0, KT>([&](auto t_c) {
                     constexpr int T = T0 + decltype(t_c)::value, SLOT = T % D;
-                    if constexpr (!kLast || (T + D < KS)) {
+                    if constexpr ((!kLast || (T + D < KS)) && !(PETIT_ABLATE_N32 & 2)) {
 #pragma unroll
                         for (int nt = 0; nt < 2 * NP; ++nt)
                             wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
@@ -376,8 +404,10 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
 #endif
         }
 
+    if constexpr (PETIT_ABLATE_N32 & 16)
+        return;
     // --- epilogue: the 32x32 accumulator layout of gemm_wide.hpp
-    const unsigned m_base = m0 + m_l;
+    const unsigned m_base = m0 + wm * (32 * MB) + m_l;
     if (gridDim.z > 1) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)

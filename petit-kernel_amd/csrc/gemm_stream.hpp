@@ -153,8 +153,10 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
             make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
         const __amdgpu_buffer_rsrc_t s_rsrc =
             make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
-        const __amdgpu_buffer_rsrc_t a_rsrc =
-            make_rsrc((const char *)p.a + (size_t)m0 * p.k * 2, rows * p.k * 2);
+        const char *a_base = (const char *)p.a + (size_t)m0 * p.k * 2;
+        if constexpr (ABL & 32) // tools/ablate: every workgroup reads its own copy of A (is the shared A a hot spot in L2?)
+            a_base += (size_t)(blockIdx.x & 63u) * p.m * p.k * 2;
+        const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, rows * p.k * 2);
 
         // Everything that decides validity lives in the VGPR offset (bounds
         // checked on every generation); the SGPR offset only walks along K.

@@ -67,7 +67,8 @@ constexpr int kNativeAm = -2;
 // per wave (2 NP), warp_partition_n = WAVES
 constexpr int kWideAm = -3;
 // the native-FP4 kernels on the 32x32x64 block-scaled MFMA (gemm_native32.hpp): code 13; fields as kWideAm; pa = 1: activations
-// quantised to MXFP8 (mfma_type 2), pa = 2: to MXFP4 (mfma_type 6: FP4 x FP4); opt-in, never a default
+// quantised to MXFP8 (mfma_type 2), pa = 2: to MXFP4 (mfma_type 6: FP4 x FP4); warp_partition_m = WM waves along M (tile_m =
+// MB * WM m32-blocks per workgroup); opt-in, never a default
 constexpr int kNative32Am = -4;
 constexpr bool is_native_am(int am) { return am == kNativeAm || am == kNative32Am; }
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with

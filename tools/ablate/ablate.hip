@@ -32,6 +32,7 @@ extern "C" int ablate_launch(int variant, int abl, void *c, const void *a, const
         case 7: launch<AT, MT, NT, WN, WK, D, AM, 7>(g, st); return 0;        \
         case 8: launch<AT, MT, NT, WN, WK, D, AM, 8>(g, st); return 0;        \
         case 16: launch<AT, MT, NT, WN, WK, D, AM, 16>(g, st); return 0;      \
+        case 32: launch<AT, MT, NT, WN, WK, D, AM, 32>(g, st); return 0;      \
         default: return -1;                                           \
         }                                                             \
     }

@@ -18,13 +18,13 @@ packed = [(torch.randint(-2 ** 31, 2 ** 31 - 1, (n // 16, 2 * k), generator=gen,
 gs = torch.ones(1, device=dev)
 stream = torch.cuda.Stream(dev)
 names = {0: "full", 1: "no A loads", 2: "no unpack", 3: "no A, no unpack", 4: "no mfma", 5: "no A, no mfma",
-         7: "loads of W/scales only", 8: "empty kernel"}
+         7: "loads of W/scales only", 8: "empty kernel", 32: "full, private copy of A per workgroup"}
 out = {}
 for m in ms:
-    a = torch.randn((m, k), device=dev).bfloat16()
+    a = torch.randn((64 * m, k), device=dev).bfloat16()   # (abl 32 reads copy blockIdx % 64; the others the first m rows)
     c = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
     for variant in ((0, 1) if m == 1 else (2, 3)):
-        for abl in (0, 1, 2, 3, 4, 5, 7, 8):
+        for abl in (0, 1, 2, 3, 4, 5, 7, 8, 32):
             def launch(i):
                 b, sp = packed[i % copies]
                 rc = lib.ablate_launch(variant, abl, C.c_void_p(c.data_ptr()), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
