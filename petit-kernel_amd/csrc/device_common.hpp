@@ -200,6 +200,36 @@ template <class AT> __device__ __forceinline__ uint2 finish4(const f32x4 v, cons
     return o;
 }
 
+// Large-M epilogue through LDS.  C^T = W . A^T leaves a lane with 4 consecutive n of one row (8 bytes), so direct stores
+// write C in 16- or 32-byte pieces of 16 / 32 different rows per instruction: every 128-byte line of C is touched by 4-8
+// requests (measured on the native kernel, gate_up M = 512: 24-49 us of a 200 us launch went away with the stores,
+// tools/ablate_native32.sh).  Instead every wave drops its finished 8-byte pieces into a [BM][BN] 16-bit image of the
+// workgroup's C tile in LDS (rows padded by 16 B: a ds_write_b64 of 16 rows and a ds_read_b128 along a row are both
+// conflict-free), and after one barrier the workgroup stores whole rows: 16 bytes per lane, BN / 8 consecutive lanes per
+// row, i.e. full cache lines.
+template <int BN> struct CTile {
+    static constexpr int kStrideU4 = BN / 8 + 1; // 16-byte units per row, one of them padding
+    static constexpr int u4(int bm) { return bm * kStrideU4; }
+};
+template <int BN> __device__ __forceinline__ void c_tile_put(u32x4 *img, unsigned row, unsigned col, uint2 v) {
+    *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(img) + row * (CTile<BN>::kStrideU4 * 16) + col * 2) = v;
+}
+// rows [0, rows_valid) x columns [0, cols_valid) of the image -> C[m0 + row][n0 + col]; cols_valid is a multiple of 8
+template <int BM, int BN, int THREADS>
+__device__ __forceinline__ void c_tile_store(const u32x4 *img, void *c, unsigned ldc, unsigned m0, unsigned n0, unsigned rows_valid,
+                                             unsigned cols_valid, unsigned tid) {
+    constexpr int kPerRow = BN / 8;
+#pragma unroll
+    for (int u = 0; u < BM * kPerRow; u += THREADS) {
+        const unsigned unit = u + tid, row = unit / kPerRow, cu = unit % kPerRow;
+        if ((BM * kPerRow) % THREADS != 0 && unit >= (unsigned)(BM * kPerRow))
+            break;
+        if (row < rows_valid && cu * 8 < cols_valid)
+            *reinterpret_cast<u32x4 *>(reinterpret_cast<char *>(c) + ((size_t)(m0 + row) * ldc + n0 + cu * 8) * 2) =
+                img[row * CTile<BN>::kStrideU4 + cu];
+    }
+}
+
 // SiLU-mul epilogue (petit_epilogue.activation = 1): `gate` holds 4 consecutive columns j of the first half of
 // the GEMM's N, `up` the same columns of the second half; out[j] = silu(y_gate[j]) * y_up[j], y = acc*gs + bias,
 // rounded once.  bias (if any) spans the full N: gate part at n, up part at n + n_half.

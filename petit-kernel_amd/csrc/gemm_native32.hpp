@@ -48,13 +48,27 @@ template <int ACT> __host__ __device__ inline size_t native32_ws_bytes(unsigned 
 // One thread = 8 consecutive k of one row; the 4 threads of a quad share one 32-k block.
 template <class AT, int ACT>
 __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsigned char *ws, unsigned m, unsigned k) {
-    const size_t units = (size_t)m * (k / 8);
+    // grid = (ceil(K / 8 / (4 * 256)), M): blockIdx.y is the row -- no division in the address arithmetic -- and a thread owns
+    // four 8-element columns 256 apart, all four loads requested before the first is used
     const unsigned row_bytes = k / 8 * ACT;
     unsigned char *qa = ws;
     unsigned char *qs = ws + (size_t)m * row_bytes;
-    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x) {
-        const unsigned row = (unsigned)(u / (k / 8)), c8 = (unsigned)(u % (k / 8)); // 8-element column
-        const u32x4 raw = reinterpret_cast<const u32x4 *>(a)[u];
+    constexpr int kIlp = 4;
+    const unsigned row = blockIdx.y, cols = k / 8;
+    const u32x4 *const a_row = reinterpret_cast<const u32x4 *>(a) + (size_t)row * cols;
+    {
+      u32x4 raws[kIlp];
+#pragma unroll
+      for (int j = 0; j < kIlp; ++j) {
+          const unsigned c = (blockIdx.x * kIlp + j) * 256 + threadIdx.x;
+          raws[j] = c < cols ? a_row[c] : u32x4{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int j = 0; j < kIlp; ++j) {
+        const unsigned c8 = (blockIdx.x * kIlp + j) * 256 + threadIdx.x; // 8-element column
+        if (c8 >= cols) // (K / 8 is a multiple of 16: the 16 lanes of a k-tile leave together)
+            break;
+        const u32x4 raw = raws[j];
         float v[8];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -104,8 +118,12 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
             q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[6], v[7], scale, 3);
             *reinterpret_cast<unsigned *>(qa + ((size_t)kt * m + row) * 64 + col16 * 4) = q;
         }
-        if ((c8 & 3) == 0)
-            qs[((size_t)kt * m + row) * 4 + (c8 / 4) % 4] = (unsigned char)sbyte;
+        // the four scale bytes of a row's k-tile leave as ONE dword (byte stores are the slow path of the memory pipeline):
+        // the 16 lanes of a k-tile are consecutive, the first lane of each quad holds the quad's byte
+        const unsigned s1 = __shfl_down(sbyte, 4, 16), s2 = __shfl_down(sbyte, 8, 16), s3 = __shfl_down(sbyte, 12, 16);
+        if (col16 == 0)
+            *reinterpret_cast<unsigned *>(qs + ((size_t)kt * m + row) * 4) = sbyte | (s1 << 8) | (s2 << 16) | (s3 << 24);
+      }
     }
 }
 
@@ -140,8 +158,19 @@ template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, in
     static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
     static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && (PF == 1 || PF == 2), "stage = 1 or 2 k-tiles, 1 or 2 stages ahead");
     static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
-    static_assert(NBUF * kStageU4 * 16 <= 160 * 1024, "LDS budget");
+    static constexpr int BN = 32 * NP * WAVES;
+    static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
+    static constexpr int kSmemU4 = NBUF * kStageU4 > kCTileU4 ? NBUF * kStageU4 : kCTileU4;
+    static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
 };
+
+// W refills (wave-loads) the stage that starts at tile t_first of a span issues: the tiles whose slot is needed again
+constexpr int n32_stage_refills(bool last_span, int t_first, int kt, int d, int ks, int np) {
+    int n = 0;
+    for (int t = t_first; t < t_first + kt; ++t)
+        n += (!last_span || t + d < ks) ? 2 * np : 0;
+    return n;
+}
 
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const GemmArgs p, const unsigned char *ws) {
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
     constexpr int kFragU4 = ACT == 8 ? 2 : 1; // 16-byte units of one activation operand
 
     // NBUF stages of [KT tile images][KT scale arrays]
-    __shared__ u32x4 smem[NBUF * Cfg::kStageU4];
+    __shared__ u32x4 smem[Cfg::kSmemU4];
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
@@ -362,12 +391,18 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
                     __syncthreads();
                 cur_buf ^= 1u;
             } else {
-                // the next stage (requested a stage ago) must have landed; the one requested at the top of this stage stays in
-                // flight: "at most kStageLoads outstanding" retires everything older (issue order).  W refills come AFTER the wait
-                // so that the count stays exact.
+                // the next stage (requested a stage ago) must have landed.  Loads retire in issue order, and after that request
+                // came the PREVIOUS stage's W refills and the request at the top of this stage: both stay in flight (a wait for
+                // "at most kStageLoads outstanding" would also drain the refills one stage after they were issued, whatever the
+                // ring depth D -- the weight stream then pays an L2 round trip per stage).  The count is exact per stage: the
+                // first stage of a span follows the last stage of a non-last span (all refills issued) or the prologue (which
+                // drained everything: a larger count waits for nothing, and nothing is pending).
                 if constexpr (kNextStage) {
+                    constexpr int kPrevRefills = (PETIT_ABLATE_N32 & 2) ? 0
+                                                 : S == 0           ? 2 * NP * KT
+                                                                    : n32_stage_refills(kLast, T0 - KT, KT, D, KS, NP);
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kStageLoads) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kStageLoads + kPrevRefills) : "memory");
                     __builtin_amdgcn_s_barrier();
 #endif
                 }
@@ -443,20 +478,25 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
                 }
         return;
     }
+    // plain / bias epilogue: through an LDS image of the C tile, whole rows out (c_tile_store, device_common.hpp).  The stages
+    // are dead: every wave is past its last fragment read and (barrier) its last DMA has landed.
+    __syncthreads();
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int np = 0; np < NP; ++np)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const unsigned m = m_base + mb * 32;
                 const unsigned nt = 2 * np + (u >> 1);
                 const unsigned n = (nt0 + nt) * 16 + (u & 1) * 8 + 4 * h;
-                if (m < p.m && nt < valid_nt) {
-                    const f32x4 v = f32x4{acc[mb][np][4 * u], acc[mb][np][4 * u + 1], acc[mb][np][4 * u + 2], acc[mb][np][4 * u + 3]};
-                    *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
-                }
+                const f32x4 v = f32x4{acc[mb][np][4 * u], acc[mb][np][4 * u + 1], acc[mb][np][4 * u + 2], acc[mb][np][4 * u + 3]};
+                if (nt < valid_nt) // (bias is read at n: only for columns that exist)
+                    c_tile_put<Cfg::BN>(smem, (wm * MB + mb) * 32 + m_l, (wn * 2 * NP + nt) * 16 + (u & 1) * 8 + 4 * h,
+                                        finish4<AT>(v, gs, p.bias, n));
             }
+    __syncthreads();
+    const unsigned n0 = bn * Cfg::BN;
+    c_tile_store<Cfg::BM, Cfg::BN, Cfg::kThreads>(smem, p.c, p.n, m0, n0, rows, n0 < p.n ? min((unsigned)Cfg::BN, p.n - n0) : 0u, tid);
 }
 
 } // namespace petit_amd
