@@ -153,7 +153,8 @@ double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k,
         resident = acc <= 8 && s.mt <= 4 ? 1.14 : 1.0;
     } else {
         t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
-           : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97 : 0.09 * acc + 0.2;
+           : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97
+           : s.mt == 4 && s.nt == 5 ? 1.43 : s.mt == 8 && s.nt == 4 ? 1.92 : 0.09 * acc + 0.2; // (64x320: qkv M = 512 91.6 us / 64 steps; 128x256: down 215 us / 112)
         if (e.fmt == kFmtMx)
             t1 *= 0.75; // no group-scale multiplies in the unpack
         resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
