@@ -124,18 +124,43 @@ at::Tensor mul_mxfp4_a16(const at::Tensor &A, const at::Tensor &B, const at::Ten
     return mul_a16(true, A, B, s, gs, m, n, k, solution_id, bias, activation);
 }
 
+// Shape functions for the Meta key (FakeTensor / torch.compile tracing, torch.export): outputs of the right shape, dtype and
+// device, nothing launched -- the ops trace as opaque calls instead of breaking the graph.
+at::Tensor repack_nvfp4_meta(const at::Tensor &q, int64_t n, int64_t k) { return at::empty({n / kLayoutN, k * kLayoutN / kPack}, q.options()); }
+at::Tensor process_nvfp4_scales_meta(const at::Tensor &s, int64_t n, int64_t k) { return at::empty({n, k / 16}, s.options()); }
+at::Tensor process_mxfp4_scales_meta(const at::Tensor &s, int64_t n, int64_t k) { return at::empty({n / 32, k}, s.options()); }
+at::Tensor mul_a16_meta(const at::Tensor &A, const at::Tensor &, const at::Tensor &, const at::Tensor &, int64_t m, int64_t n, int64_t, int64_t,
+                        const std::optional<at::Tensor> &, int64_t activation) {
+    TORCH_CHECK(A.scalar_type() == at::kBFloat16 || A.scalar_type() == at::kHalf, "A must be bfloat16 or float16.");
+    return at::empty({m, activation ? n / 2 : n}, A.options());
+}
+
 } // namespace
 
-// Registered as catch-all kernels (no dispatch key): a CPU tensor then reaches the checks above and gets the reference's
-// own error text ("... is not on GPU", fp4.cc:50-52) instead of a dispatcher message.
+// Schemas first, then one implementation per backend key.  The CPU key gets the SAME functions as the GPU key: a CPU
+// tensor then reaches the checks above and gets the reference's own error text ("... is not on GPU", fp4.cc:50-52)
+// instead of a dispatcher message.  (torch-ROCm devices dispatch on the CUDA key.)
 TORCH_LIBRARY(petit_kernel, m) {
-    m.def("repack_nvfp4(Tensor b_q_weight, int size_n, int size_k) -> Tensor", &repack_nvfp4);
-    m.def("process_nvfp4_scales(Tensor scales, int size_n, int size_k) -> Tensor", &process_nvfp4_scales);
-    m.def("process_mxfp4_scales(Tensor scales, int size_n, int size_k) -> Tensor", &process_mxfp4_scales);
+    m.def("repack_nvfp4(Tensor b_q_weight, int size_n, int size_k) -> Tensor");
+    m.def("process_nvfp4_scales(Tensor scales, int size_n, int size_k) -> Tensor");
+    m.def("process_mxfp4_scales(Tensor scales, int size_n, int size_k) -> Tensor");
     m.def("mul_nvfp4_a16(Tensor A, Tensor B, Tensor s, Tensor global_scale, int size_m, int size_n, int size_k, int solution_id, "
-          "Tensor? bias=None, int activation=0) -> Tensor",
-          &mul_nvfp4_a16);
+          "Tensor? bias=None, int activation=0) -> Tensor");
     m.def("mul_mxfp4_a16(Tensor A, Tensor B, Tensor s, Tensor global_scale, int size_m, int size_n, int size_k, int solution_id, "
-          "Tensor? bias=None, int activation=0) -> Tensor",
-          &mul_mxfp4_a16);
+          "Tensor? bias=None, int activation=0) -> Tensor");
+}
+#define PETIT_IMPL_REAL(m)                                      \
+    m.impl("repack_nvfp4", &repack_nvfp4);                      \
+    m.impl("process_nvfp4_scales", &process_nvfp4_scales);      \
+    m.impl("process_mxfp4_scales", &process_mxfp4_scales);      \
+    m.impl("mul_nvfp4_a16", &mul_nvfp4_a16);                    \
+    m.impl("mul_mxfp4_a16", &mul_mxfp4_a16);
+TORCH_LIBRARY_IMPL(petit_kernel, CUDA, m) { PETIT_IMPL_REAL(m) }
+TORCH_LIBRARY_IMPL(petit_kernel, CPU, m) { PETIT_IMPL_REAL(m) }
+TORCH_LIBRARY_IMPL(petit_kernel, Meta, m) {
+    m.impl("repack_nvfp4", &repack_nvfp4_meta);
+    m.impl("process_nvfp4_scales", &process_nvfp4_scales_meta);
+    m.impl("process_mxfp4_scales", &process_mxfp4_scales_meta);
+    m.impl("mul_nvfp4_a16", &mul_a16_meta);
+    m.impl("mul_mxfp4_a16", &mul_a16_meta);
 }

@@ -595,6 +595,32 @@ def test_compiled_and_ctypes_bindings_agree(pk):
                    oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
+def test_compiled_ops_trace_without_graph_break(pk):
+    """torch.compile(fullgraph=True) through the compiled operator layer: the Meta kernels let dynamo trace
+    torch.ops.petit_kernel.mul_nvfp4_a16 as one opaque call (backend "eager": no code generator involved), and the traced
+    function returns what the eager call returns."""
+    from petit_kernel import compiled
+    assert compiled.available(), compiled.why_unavailable()
+    m, n, k = 7, 128, 1024
+    a, q, s, gs = random_problem("nv", m, n, k, 4711, True)
+    ad, qd = from_bits(a, torch.bfloat16).to(DEV), torch.from_numpy(q).to(DEV).view(torch.int32)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+    b = compiled.repack_nvfp4(qd, n, k)
+    sp = compiled.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+
+    def layer(x):
+        return torch.ops.petit_kernel.mul_nvfp4_a16(x * 1.0, b, sp, gsd, m, n, k, -1) + 1.0
+
+    try:
+        traced = torch.compile(layer, backend="eager", fullgraph=True)
+        out = traced(ad)
+    except Exception as exc:  # noqa: BLE001 -- dynamo itself unavailable on this build
+        if "petit_kernel" in str(exc):
+            raise
+        pytest.skip(f"torch.compile unavailable here: {type(exc).__name__}")
+    assert torch.equal(out.view(torch.int16), layer(ad).view(torch.int16))
+
+
 def test_offline_repack_matches_device(pk):
     """petit_kernel.offline (CPU, checkpoint-side tooling) == the device repack, bit for bit, and the GEMM
     accepts the CPU-packed tensors."""

@@ -357,6 +357,40 @@ def test_ingest_of_reference_packed_tensors(n, k):
     assert torch.equal(got_mx, petit_kernel.offline.process_mxfp4_scales_cpu(torch.from_numpy(mx), n, k))
 
 
+def test_compiled_ops_have_shape_functions_for_tracing():
+    """torch.ops.petit_kernel.* carry Meta kernels (csrc/torch_binding.cpp): with meta tensors, and under FakeTensorMode with
+    fake GPU tensors (what torch.compile / torch.export trace with), every op returns the shape, dtype and device the real
+    kernel would, and launches nothing -- this runs on a box without a GPU.  A CPU tensor still gets the reference's own
+    error text (lib/pybind/fp4.cc:50-52), not a dispatcher message."""
+    from petit_kernel import compiled
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    if not compiled.available():
+        pytest.skip(f"compiled binding not built: {compiled.why_unavailable()}")
+    m, n, k = 5, 256, 1024
+
+    def run(dev):
+        a = torch.empty((m, k), dtype=torch.bfloat16, device=dev)
+        q = torch.empty((n, k // 8), dtype=torch.int32, device=dev)
+        b = torch.ops.petit_kernel.repack_nvfp4(q, n, k)
+        assert b.shape == (n // 16, 2 * k) and b.dtype == torch.int32
+        s = torch.ops.petit_kernel.process_nvfp4_scales(torch.empty((n, k // 16), dtype=torch.float8_e4m3fn, device=dev), n, k)
+        assert s.shape == (n, k // 16) and s.dtype == torch.float8_e4m3fn
+        sx = torch.ops.petit_kernel.process_mxfp4_scales(torch.empty((n, k // 32), dtype=torch.uint8, device=dev), n, k)
+        assert sx.shape == (n // 32, k) and sx.dtype == torch.uint8
+        gs = torch.empty(1, device=dev)
+        c = torch.ops.petit_kernel.mul_nvfp4_a16(a, b, s, gs, m, n, k, -1)
+        assert c.shape == (m, n) and c.dtype == a.dtype and c.device == a.device
+        c = torch.ops.petit_kernel.mul_mxfp4_a16(a.half(), b, sx, gs, m, n, k, -1, None, 1)
+        assert c.shape == (m, n // 2) and c.dtype == torch.float16
+        return c
+
+    assert run("meta").device.type == "meta"
+    with FakeTensorMode():
+        assert run("cuda").device.type == "cuda"
+    with pytest.raises(RuntimeError, match="not on GPU"):
+        torch.ops.petit_kernel.repack_nvfp4(torch.zeros((n, k // 8), dtype=torch.int32), n, k)
+
+
 def test_heuristic_stays_close_to_the_measured_best():
     """Where the arch table has no row the heuristic decides: replayed (table disabled) against every case of the
     committed MI355X sweeps its median must stay within 1.03x of the best measured solution, 90 % of the cases within 1.2x, the worst
