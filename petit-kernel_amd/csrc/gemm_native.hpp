@@ -41,8 +41,11 @@ __device__ __forceinline__ void pin_acc(f32x4 &x) {
 #endif
 }
 
-// Workspace layout: qa[M][K] bytes (per 128-k tile: byte 32g + 16c + j holds k = 64c + 16g + j),
-// then qs[M][K/32] E8M0 bytes.
+// Workspace layout, K-TILE MAJOR: qa[K/128][M][128] bytes (inside a tile: byte 32g + 16c + j holds k = 64c + 16g + j), then
+// qs[K/128][M][4] E8M0 bytes -- the activation tile and the scale dwords of a workgroup and k-tile are contiguous runs, so the
+// direct-to-LDS wave-loads read whole cache lines (with row-major scales qs[M][K/32] the 64 lanes of a scale load touched
+// 64 different lines for 256 useful bytes; see gemm_native32.hpp for the measurement that prompted this).  Rows >= M of the
+// last m-block read the next tile's rows (or zeros past the end): they only feed output columns that are never stored.
 __host__ __device__ inline size_t native_ws_bytes(unsigned m, unsigned k) { return (size_t)m * k + (size_t)m * (k / 32); }
 // the same rounded up to 256 B: where the fp32 slabs of a K split start inside a call's workspace
 __host__ __device__ inline size_t native_ws_aligned(unsigned m, unsigned k) { return (native_ws_bytes(m, k) + 255) & ~(size_t)255; }
@@ -92,9 +95,9 @@ __global__ __launch_bounds__(256) void quantize_act_kernel(const void *a, unsign
         const unsigned off = 32 * ((col16 & 7) >> 1) + 16 * (col16 >> 3) + 8 * (col16 & 1);
         uint2 o;
         o.x = (unsigned)q0, o.y = (unsigned)q1;
-        *reinterpret_cast<uint2 *>(qa + (size_t)row * k + kt * 128 + off) = o;
+        *reinterpret_cast<uint2 *>(qa + ((size_t)kt * m + row) * 128 + off) = o;
         if ((c8 & 3) == 0)
-            qs[(size_t)row * (k / 32) + c8 / 4] = (unsigned char)sbyte;
+            qs[((size_t)kt * m + row) * 4 + (c8 / 4) % 4] = (unsigned char)sbyte;
     }
 }
 
@@ -166,9 +169,12 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     auto rel_tile = [&](int nt) -> unsigned {
         return ((unsigned)nt < valid_nt) ? physical_tile(nt0 + nt, ntiles, p.act) - pt0 : span_tiles; // beyond: out of range
     };
-    // quantised activations and their scales (rows beyond M read as zeros: 0 * 2^-127)
-    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * p.k, rows * p.k);
-    const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + (size_t)p.m * p.k + (size_t)m0 * (p.k / 32), rows * (p.k / 32));
+    // quantised activations and their scales, k-tile major: tile kt of this m-block starts (kt M + m0) rows of 128 (data) /
+    // 4 (scales) bytes into its region; the descriptors end with the region
+    const size_t qa_bytes = (size_t)p.m * p.k, qs_bytes = (size_t)p.m * (p.k / 32);
+    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * 128, (unsigned)(qa_bytes - (size_t)m0 * 128));
+    const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + qa_bytes + (size_t)m0 * 4, (unsigned)(qs_bytes - (size_t)m0 * 4));
+    const unsigned qa_tile = p.m * 128, qs_tile = p.m * 4; // bytes from one k-tile to the next
 
     // Per-lane offsets are ONE VGPR each; everything that varies with the n-tile, the k-step or the
     // staging unit rides in the SGPR offset, which gfx950 includes in the buffer range check (probed,
@@ -179,17 +185,17 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     // position l%8, which receives unit (l%8) ^ ((row/2)%8).  Scales: wave w covers rows 64w .. 64w+63, one dword
     // per lane (waves beyond BM read out of range and park zeros in the unused tail of the scale array).
     const unsigned dma_row0 = wave * 8 + (lane >> 3);
-    const unsigned dma_voff = dma_row0 * p.k + (((lane & 7u) ^ ((dma_row0 >> 1) & 7u)) * 16);
-    const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * (p.k / 32) : kOob;
+    const unsigned dma_voff = dma_row0 * 128 + (((lane & 7u) ^ ((dma_row0 >> 1) & 7u)) * 16);
+    const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * 4 : kOob;
     auto dma_stage = [&](unsigned kt, unsigned buf) {
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass knows neither the builtin nor the LDS address space)
         u32x4 *const data = smem + buf * Cfg::kDataU4;
 #pragma unroll
         for (int i = 0; i < Cfg::kDataLoads; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * WAVES + wave) * 64), 16,
-                                                     dma_voff, i * (8 * WAVES) * p.k + kt * 128, 0, 0);
+                                                     dma_voff, i * (8 * WAVES) * 128 + kt * qa_tile, 0, 0);
         u32x4 *const sc = smem + 2 * Cfg::kDataU4 + buf * Cfg::kScaleU4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, kt * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, kt * qs_tile, 0, 0);
 #else
         (void)kt, (void)buf;
 #endif
@@ -224,8 +230,10 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             const unsigned cur = kt & 1u;
             const u32x4 *const a_cur = smem + cur * Cfg::kDataU4;
             const unsigned char *const a_cur_bytes = reinterpret_cast<const unsigned char *>(smem + 2 * Cfg::kDataU4 + cur * Cfg::kScaleU4);
-            if constexpr (kNextA)
+            if constexpr (kNextA) {
                 dma_stage(kt + 1, cur ^ 1u); // everybody left that buffer at the barrier that ended the previous step
+                __builtin_amdgcn_sched_barrier(0); // (issued BEFORE this step's W refill: the wait that ends the step counts on it)
+            }
             if constexpr (!kLast && T == KS - 1) { // next span's scale records: one step ahead is enough
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt)
@@ -289,8 +297,17 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                             (int)srec[nt].d[T / 4], 0, ascale);
                 }
             }
-            if constexpr (kNextA)
-                __syncthreads();
+            // The next activation tile must have landed -- nothing else.  Loads retire in issue order and the last loads of the
+            // step are its W refill, which stays in flight: __syncthreads() (= vmcnt(0)) drained the refill at every step, so
+            // the weight ring covered ONE step whatever its depth, and a step (16 MFMAs, ~0.25 us) took an L2 round trip
+            // (~0.5 us: 64 steps x 7 rounds x 0.5 us = the 223 us measured at gate_up, M = 512).
+            if constexpr (kNextA) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kRefill ? NTW : 0) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#endif
+            }
             // Pin the step: left alone, LLVM sinks all MT*NTW*KS MFMAs of a span below its last barrier
             // and hoists every step's LDS traffic above them (hundreds of spilled VGPRs, no overlap).
             __builtin_amdgcn_sched_barrier(0);

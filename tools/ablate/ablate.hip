@@ -13,7 +13,8 @@ template <class AT, int MT, int NT, int WN, int WK, int D, int AM, int ABL> stat
                        b.act, b.c, b.gs, b.bias, b.workspace);
 }
 
-// variant: (AT,MT,NT,WN,WK,D,AM) 0 = bfp (1,1,1,8,8,1) [bench default]  1 = bf16 (1,1,1,8,8,1)  2 = bf16 (1,2,1,4,4,16)  3 = bf16 (1,2,1,8,4,0)
+// variant: (AT,MT,NT,WN,WK,D,AM) 0 = bfp (1,1,1,8,8,1)  1 = bf16 (1,1,1,8,8,1)  2 = bf16 (1,2,1,4,4,16)  3 = bf16 (1,2,1,8,4,0)
+//          4 = (1,2,1,4,8,16) deeper ring  5 = (1,1,1,8,8,16) the M = 1 wave geometry  6 = (1,2,1,8,4,16) eight K waves
 extern "C" int ablate_launch(int variant, int abl, void *c, const void *a, const void *w, const void *s, const float *gs,
                              unsigned m, unsigned n, unsigned k, void *stream, void *stamps) {
     GemmArgs g{};
@@ -40,5 +41,8 @@ extern "C" int ablate_launch(int variant, int abl, void *c, const void *a, const
     CASE(1, Bf16, 1, 1, 1, 8, 8, 1)
     CASE(2, Bf16, 1, 2, 1, 4, 4, 16)
     CASE(3, Bf16, 1, 2, 1, 8, 4, 0)
+    CASE(4, Bf16, 1, 2, 1, 4, 8, 16)
+    CASE(5, Bf16, 1, 1, 1, 8, 8, 16)
+    CASE(6, Bf16, 1, 2, 1, 8, 4, 16)
     return -1;
 }

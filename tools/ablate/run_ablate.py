@@ -23,7 +23,8 @@ out = {}
 for m in ms:
     a = torch.randn((64 * m, k), device=dev).bfloat16()   # (abl 32 reads copy blockIdx % 64; the others the first m rows)
     c = torch.empty((m, n), dtype=torch.bfloat16, device=dev)
-    for variant in ((0, 1) if m == 1 else (2, 3)):
+    variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else ((0, 1) if m == 1 else (2, 3))
+    for variant in variants:
         for abl in (0, 1, 2, 3, 4, 5, 7, 8, 32):
             def launch(i):
                 b, sp = packed[i % copies]
