@@ -157,7 +157,6 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     const unsigned valid_nt = nt0 < ntiles ? min((unsigned)NTW, ntiles - nt0) : 0u;
     const unsigned w_row_bytes = ktiles * kTileBytes;
     const unsigned s_row_bytes = p.k / 2;
-    const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
     // logical -> physical n-tiles (identity, or gate/up pairs for the SiLU-mul epilogue; device_common.hpp)
     const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
     const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
