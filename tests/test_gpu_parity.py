@@ -1113,7 +1113,7 @@ def quantize_act_mxfp4(a_f32: np.ndarray) -> np.ndarray:
 
 
 @pytest.mark.parametrize("is_bf16", [True, False])
-@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512)])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512), (5, 64, 1024), (1, 128, 512), (257, 160, 1280)])
 def test_native_fp4_activations(pk, m, n, k, is_bf16):
     """FP4 x FP4 (MXFP4 weights raw, activations quantised on the fly to MXFP4: the 10 PFLOP/s instruction).  Opt-in,
     ids carry mfma_type 6.  (1) exact semantics: against the oracle run on the CPU-emulated MXFP4 activations the kernel
@@ -1149,7 +1149,7 @@ def test_native_fp4_activations(pk, m, n, k, is_bf16):
 
 
 @pytest.mark.parametrize("is_bf16", [True, False])
-@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512)])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512), (5, 64, 1024), (1, 128, 512), (257, 160, 1280)])
 def test_native_mxfp4(pk, m, n, k, is_bf16):
     a_bits, q, s, gs = random_problem("mx", m, n, k, 4242 + m + n + k, is_bf16)
     dtype = torch.bfloat16 if is_bf16 else torch.float16
