@@ -56,15 +56,14 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
     constexpr int kIlp = 4;
     const unsigned row = blockIdx.y, cols = k / 8;
     const u32x4 *const a_row = reinterpret_cast<const u32x4 *>(a) + (size_t)row * cols;
-    {
-      u32x4 raws[kIlp];
+    u32x4 raws[kIlp];
 #pragma unroll
-      for (int j = 0; j < kIlp; ++j) {
-          const unsigned c = (blockIdx.x * kIlp + j) * 256 + threadIdx.x;
-          raws[j] = c < cols ? a_row[c] : u32x4{0u, 0u, 0u, 0u};
-      }
+    for (int j = 0; j < kIlp; ++j) {
+        const unsigned c = (blockIdx.x * kIlp + j) * 256 + threadIdx.x;
+        raws[j] = c < cols ? a_row[c] : u32x4{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
-      for (int j = 0; j < kIlp; ++j) {
+    for (int j = 0; j < kIlp; ++j) {
         const unsigned c8 = (blockIdx.x * kIlp + j) * 256 + threadIdx.x; // 8-element column
         if (c8 >= cols) // (K / 8 is a multiple of 16: the 16 lanes of a k-tile leave together)
             break;
@@ -123,7 +122,6 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
         const unsigned s1 = __shfl_down(sbyte, 4, 16), s2 = __shfl_down(sbyte, 8, 16), s3 = __shfl_down(sbyte, 12, 16);
         if (col16 == 0)
             *reinterpret_cast<unsigned *>(qs + ((size_t)kt * m + row) * 4) = sbyte | (s1 << 8) | (s2 << 16) | (s3 << 24);
-      }
     }
 }
 
