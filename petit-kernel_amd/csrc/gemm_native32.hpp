@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
 //   KT   k-tiles per barrier ("stage"): the quantised activation tile is small (128 / 64 bytes per row and k-tile), and with
 //        zero unpack work a k-tile is only 2*MB*NP MFMAs, so one barrier per tile leaves the wave waiting on it.
 //   PF   stages requested ahead (NBUF = PF + 1 LDS stages): 1 = the next stage is requested at the top of a stage and waited
-//        for at its end; 2 = two ahead, in flight across the barrier (raw s_barrier + counted vmcnt, as gemm_wide.hpp PF = 2).
+//        for at its end; 2 / 3 = that many ahead, in flight across the barrier (raw s_barrier + counted vmcnt).  Loads retire
+//        in issue order, so the W refills can stay in flight for PF - 1 stages only: PF is also the weight ring's real depth.
 //        Unlike the dequant kernels (power-limited) this kernel was latency-bound: a stage took the L2 round
 //        trip (~1900 cycles) for 512 cycles of MFMA work.
 //   WM   waves along M (1 or 2): the workgroup is WM x WAVES waves, every wave owns MB m32-blocks x NP n-pairs, the WM waves
@@ -154,7 +155,7 @@ template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, in
     static_assert((kRowsPerLoad * kWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
     static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4);   // one stage: KT tile images, then their KT scale arrays
     static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
-    static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && (PF == 1 || PF == 2), "stage = 1 or 2 k-tiles, 1 or 2 stages ahead");
+    static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && PF >= 1 && PF <= 3, "stage = 1 or 2 k-tiles, 1 to 3 stages ahead");
     static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
     static constexpr int BN = 32 * NP * WAVES;
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
@@ -163,7 +164,10 @@ template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, in
 };
 
 // W refills (wave-loads) the stage that starts at tile t_first of a span issues: the tiles whose slot is needed again
+// (t_first < 0: a stage of the PREVIOUS span, which is never a last span: every tile is refilled)
 constexpr int n32_stage_refills(bool last_span, int t_first, int kt, int d, int ks, int np) {
+    if (t_first < 0)
+        return 2 * np * kt;
     int n = 0;
     for (int t = t_first; t < t_first + kt; ++t)
         n += (!last_span || t + d < ks) ? 2 * np : 0;
@@ -278,10 +282,10 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
     // --- prologue: stage 0 (and 1 when two are kept ahead), scale records, the W ring
     const unsigned kt_end = sp_end * KS;
     dma_stage(kt_begin, 0);
-    if constexpr (PF == 2) {
-        if (kt_begin + KT < kt_end)
-            dma_stage(kt_begin + KT, 1);
-    }
+#pragma unroll
+    for (int i = 1; i < PF; ++i)
+        if (kt_begin + i * KT < kt_end)
+            dma_stage(kt_begin + i * KT, i);
     ScaleRec<kFmtMx, KS> rec[NP][2], rec_next[NP][2];
     auto load_recs = [&](ScaleRec<kFmtMx, KS> (*dst)[2], unsigned sp) {
 #pragma unroll
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
             } else {
                 // always issued (beyond the K slice the loads are out of the descriptor's range: zeros into a stage nobody
                 // reads), so the wait below is one constant and there is no branch around the MFMA stream
-                dma_stage(kt + 2 * KT, cur_buf == 0 ? 2u : cur_buf - 1);
+                dma_stage(kt + PF * KT, cur_buf == 0 ? (unsigned)(NBUF - 1) : cur_buf - 1);
             }
             Frags fr[2];
             read_frags(stage, stage_sc, 0, fr[0]);
@@ -389,18 +393,21 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
                     __syncthreads();
                 cur_buf ^= 1u;
             } else {
-                // the next stage (requested a stage ago) must have landed.  Loads retire in issue order, and after that request
-                // came the PREVIOUS stage's W refills and the request at the top of this stage: both stay in flight (a wait for
-                // "at most kStageLoads outstanding" would also drain the refills one stage after they were issued, whatever the
-                // ring depth D -- the weight stream then pays an L2 round trip per stage).  The count is exact per stage: the
-                // first stage of a span follows the last stage of a non-last span (all refills issued) or the prologue (which
-                // drained everything: a larger count waits for nothing, and nothing is pending).
+                // the next stage (requested PF - 1 stages ago) must have landed.  Loads retire in issue order, and after that
+                // request came the W refills of the PF - 1 stages before this one and the PF - 1 requests since: all of them stay
+                // in flight (a wait for "at most kStageLoads outstanding" would also drain the refills one stage after they were
+                // issued, whatever the ring depth D -- the weight stream then pays an L2 round trip per stage).  The count is
+                // exact per stage: a stage before the first of a span belongs to a non-last span (all refills issued) or to the
+                // prologue (which drained everything: a larger count waits for nothing, and nothing is pending).
                 if constexpr (kNextStage) {
-                    constexpr int kPrevRefills = (PETIT_ABLATE_N32 & 2) ? 0
-                                                 : S == 0           ? 2 * NP * KT
-                                                                    : n32_stage_refills(kLast, T0 - KT, KT, D, KS, NP);
+                    constexpr int kPrevRefills = [] {
+                        int n = 0;
+                        for (int j = 1; j < PF; ++j)
+                            n += n32_stage_refills(kLast, T0 - j * KT, KT, D, KS, NP);
+                        return (PETIT_ABLATE_N32 & 2) ? 0 : n;
+                    }();
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::kStageLoads + kPrevRefills) : "memory");
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * Cfg::kStageLoads + kPrevRefills) : "memory");
                     __builtin_amdgcn_s_barrier();
 #endif
                 }
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const G
                             wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
                     }
                 });
-                cur_buf = cur_buf == 2 ? 0u : cur_buf + 1;
+                cur_buf = cur_buf == (unsigned)(NBUF - 1) ? 0u : cur_buf + 1;
             }
             __builtin_amdgcn_sched_barrier(0);
         });
