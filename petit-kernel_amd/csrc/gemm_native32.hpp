@@ -158,6 +158,9 @@ template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, in
     static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && PF >= 1 && PF <= 3, "stage = 1 or 2 k-tiles, 1 to 3 stages ahead");
     static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
     static constexpr int BN = 32 * NP * WAVES;
+    // 128 x 256 / 256 x 128 with a two-tile ring: asked to fit two workgroups per CU (256 registers, 128 of them accumulators):
+    // 3/4 of the operand bytes per flop of 128 x 128 AND a second workgroup to overlap with (gate_up M = 512: 158 -> 144 us)
+    static constexpr int kMinWavesPerSimd = (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2) ? 2 : 1; // (MXFP8 fragments are twice the size: spills)
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
     static constexpr int kSmemU4 = NBUF * kStageU4 > kCTileU4 ? NBUF * kStageU4 : kCTileU4;
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
@@ -175,7 +178,7 @@ constexpr int n32_stage_refills(bool last_span, int t_first, int kt, int d, int 
 }
 
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads, 1) void gemm_native32_kernel(const GemmArgs p, const unsigned char *ws) {
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_native32_kernel(const GemmArgs p, const unsigned char *ws) {
     using AT = typename Cfg::AT;
     constexpr int KS = Cfg::KS, MB = Cfg::MB, NP = Cfg::NP, WAVES = Cfg::WAVES, D = Cfg::D, ACT = Cfg::ACT;
     constexpr int KT = Cfg::KT, PF = Cfg::PF, NBUF = Cfg::NBUF, WM = Cfg::WM, kWaves = Cfg::kWaves;
