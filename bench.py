@@ -113,10 +113,10 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                 sink.flush()
     cells = Cells()
     auto = _lib.PETIT_SOLUTION_AUTO
-    for shape in ("qkv", "o", "gate_up", "down"):
+    def nv_cells(shape, ms):
         n, k = BL.LLAMA70B[shape]
         w = BL.Weights("nv", n, k, 1280, dev)
-        for m in (1, 8, 16, 512):
+        for m in ms:
             if time.time() - t0 > budget_s:
                 notes.append(f"time budget reached before {shape} M={m}")
                 break
@@ -132,6 +132,15 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                           "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"})
         del w
         torch.cuda.empty_cache()
+
+    # the bandwidth-bound cells of every shape first: measured on MI355X, a decode cell timed right after the M = 512 cells of
+    # the previous shape (1.3 kW for several seconds) reads 5-10 % slower than the same cell on a cool chip (down M = 16: 33.0
+    # vs 30.0 us) -- the sweeps behind the arch table measure decode cells on their own, so does this table
+    for shape in ("qkv", "o", "gate_up", "down"):
+        nv_cells(shape, (1, 8, 16))
+    for shape in ("qkv", "o", "gate_up", "down"):
+        n, k = BL.LLAMA70B[shape]
+        nv_cells(shape, (512,))
         if time.time() - t0 > budget_s:
             continue
         # M = 512: native-FP4 path (MXFP4 weights; activations quantised on the fly) and the vendor dense GEMM
