@@ -249,7 +249,9 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         const unsigned busy_wk = nspans < (unsigned)s.wk ? nspans : (unsigned)s.wk;
         const double busy = (double)wgs * s.wn * busy_wk;
         double score = 0.0;
-        score -= 4.0 * (am_rows(s.am) != want_am);
+        // the smallest staged activation block that holds M; a LARGER staged block (the only one some span sizes have) is still
+        // far better than fragment loads straight from L2 (5120 x 13824, KS = 4, M = 8: 20.6 us direct against ~13 staged)
+        score -= am_rows(s.am) == want_am ? 0.0 : (am_rows(s.am) >= (int)m ? 1.0 : 4.0);
         score += 0.5 * (s.am >= kBfpAm); // bf16 x NVFP4, M <= 4: the fp16 pipeline unpacks cheaper
         score += 0.5 * (s.am >= kDecodeAm); // NVFP4, M <= 4: scale applied after the MFMA, cheaper still (gemm_decode.hpp)
         score -= 1.0 * (s.nt != want_nt);
@@ -258,7 +260,10 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         // spans must divide evenly over the K waves, or some waves idle in the tail
         const unsigned per = (nspans + s.wk - 1) / s.wk;
         score -= 2.0 * (1.0 - (double)nspans / ((double)per * s.wk));
-        score += 0.01 * s.d;
+        // weight tiles in flight per wave: eight in every swept winner (NT x D = 1 x 8, 2 x 4, 4 x 2); deeper rings measured
+        // ~1 us SLOWER at M = 8 / 16, and an unseen shape picked one on the old "deeper on a tie" rule
+        // (12288 x 4096, M = 16: 11.4 us against 9.1)
+        score -= 0.3 * ((s.nt * s.d > 8) ? 1.0 : 0.0) + 0.05 * ((s.nt * s.d < 8) ? 1.0 : 0.0);
         if (score > best_score)
             best_score = score, best = &e;
     }
