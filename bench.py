@@ -19,10 +19,13 @@ Headline (the fields the driver reads; BASELINE.json configs[1], the configurati
     reported, so a short run (--steps 20 = 0.17 ms) is not a single sample.
 
 The rest of the metric ("TFLOPS + achieved HBM GB/s, M in {1,8,16,512}, Llama-70B shapes") is in `cells`
-(rank 0, N = 1 only): every (M, shape) of {1, 8, 16, 512} x {qkv, o, gate_up, down} for bf16 x NVFP4 through
-solution_id = -1, plus at M = 512 the opt-in native-FP4 path (bf16 x MXFP4) and an explicit hipBLASLt bf16 GEMM
-on a dense weight of the same shape (the reference's comparator, tools/benchmarks/matmul.py:92-165,
-matmul/rocm/matmul_hipblaslt.cc:103-123), all measured in this process with tools/benchlib.py.
+(rank 0, N = 1 only; the list is tools/benchlib.py bench_cell_plan(), shared with tests/test_gpu_parity.py::
+test_bench_cells_parity so that every timed cell is also checked against the oracle): for qkv / o / gate_up / down,
+bf16 x NVFP4 at M in {1, 4, 8, 16, 512}, fp16 x NVFP4 (the reference benchmark's default dtype, tools/benchmarks/matmul.py:92-127)
+at M in {16, 512}, fp16 x MXFP4 (BASELINE configs[3]) at M in {1, 16}, bf16 x MXFP4 at M = 512 -- all through solution_id = -1 --
+plus at M = 512 the opt-in native-FP4 class through its own default pick (solution_id = -2 / -3) and an explicit hipBLASLt
+bf16 GEMM on a dense weight of the same shape (the reference's comparator, matmul/rocm/matmul_hipblaslt.cc:103-123), all
+measured in one child process with tools/benchlib.py.
 
 Multi-GPU: the op is a single-GPU primitive with no exchange step:
 "replicas only" -- every rank runs the same workload on its own weights, no data-path
@@ -98,8 +101,11 @@ def cpu_baseline(a, gs, q, s, budget_s: float = 10.0):
 
 
 def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
-    """The whole metric: M in {1, 8, 16, 512} x the four Llama-3-70B linears, bf16 x NVFP4 through solution_id = -1;
-    at M = 512 also the native-FP4 kernels (bf16 x MXFP4, opt-in accuracy class) and hipBLASLt bf16 on a dense weight."""
+    """The whole metric, cell list shared with the parity test (tools/benchlib.py bench_cell_plan): M in {1, 4, 8, 16, 512} x
+    the four Llama-3-70B linears for bf16 x NVFP4, fp16 x NVFP4 (the reference benchmark's default dtype) at M = 16 / 512,
+    fp16 x MXFP4 at M = 1 / 16, bf16 x MXFP4 at M = 512, the native-FP4 class through ITS default pick (solution_id -2 / -3:
+    what an opted-in caller gets, quantiser launch included) and hipBLASLt bf16 on a dense weight.
+    Cells are compact (the driver keeps only the tail of stdout): id in hex, description on stderr."""
     import benchlib as BL
     from petit_kernel import _lib
     t0 = time.time()
@@ -112,93 +118,54 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                 sink.write(json.dumps(cell) + "\n")
                 sink.flush()
     cells = Cells()
-    auto = _lib.PETIT_SOLUTION_AUTO
-    def nv_cells(shape, ms):
-        n, k = BL.LLAMA70B[shape]
-        w = BL.Weights("nv", n, k, 1280, dev)
-        for m in ms:
-            if time.time() - t0 > budget_s:
-                notes.append(f"time budget reached before {shape} M={m}")
-                break
-            g = BL.Gemm(w, m, torch.bfloat16, dev)
-            sid = g.default_solution()
-            print(f"[bench] cell {shape} M={m} 0x{sid:x}", file=sys.stderr, flush=True)
-            r = g.time(auto, stream, reps=7)
-            hbm = m <= 16
-            cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x nvfp4", "us": round(r["us"], 3),
-                          "us_min": round(r["us_min"], 3), "GB/s": round(r["gbs"], 1), "TFLOPS": round(r["tflops"], 2),
-                          "bound": "hbm" if hbm else "mfma",
-                          "frac": round(r["gbs"] / BL.HBM_PEAK_GBS if hbm else r["tflops"] / BL.BF16_PEAK_TFLOPS, 4),
-                          "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"})
-        del w
-        torch.cuda.empty_cache()
-
-    # the bandwidth-bound cells of every shape first: measured on MI355X, a decode cell timed right after the M = 512 cells of
-    # the previous shape (1.3 kW for several seconds) reads 5-10 % slower than the same cell on a cool chip (down M = 16: 33.0
-    # vs 30.0 us) -- the sweeps behind the arch table measure decode cells on their own, so does this table
-    for shape in ("qkv", "o", "gate_up", "down"):
-        nv_cells(shape, (1, 8, 16))
-    for shape in ("qkv", "o", "gate_up", "down"):
-        n, k = BL.LLAMA70B[shape]
-        nv_cells(shape, (512,))
+    mode_sid = {"auto": _lib.PETIT_SOLUTION_AUTO, "native_mxfp8": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8,
+                "native_mxfp4": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4}
+    peak = {"auto": BL.BF16_PEAK_TFLOPS, "native_mxfp8": BL.FP8_PEAK_TFLOPS, "native_mxfp4": BL.FP4_PEAK_TFLOPS, "hipblaslt": BL.BF16_PEAK_TFLOPS}
+    weights = {}                         # one rotating weight set alive at a time: (shape, w)
+    for cell in BL.bench_cell_plan():
+        shape, m, a, w, mode = cell["shape"], cell["M"], cell["a"], cell["w"], cell["mode"]
         if time.time() - t0 > budget_s:
-            continue
-        # M = 512: native-FP4 path (MXFP4 weights; activations quantised on the fly) and the vendor dense GEMM
-        m = 512
-        wm = BL.Weights("mx", n, k, 1280, dev)
-        gm = BL.Gemm(wm, m, torch.bfloat16, dev)
-        sid = gm.default_solution()
-        print(f"[bench] cell {shape} M={m} mx 0x{sid:x}", file=sys.stderr, flush=True)
-        r = gm.time(auto, stream, reps=5)
-        cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x mxfp4", "us": round(r["us"], 3),
-                      "us_min": round(r["us_min"], 3), "GB/s": round(r["gbs"], 1), "TFLOPS": round(r["tflops"], 2),
-                      "bound": "mfma", "frac": round(r["tflops"] / BL.BF16_PEAK_TFLOPS, 4),
-                      "solution": f"0x{sid:x} {_lib.describe_solution(sid)}"})
-        _lib.lib.petit_enable_native_fp4(1)
+            notes.append(f"time budget reached before {shape} M={m} {a}x{w} {mode}")
+            break
+        n, k = BL.LLAMA70B[shape]
+        dtype = torch.bfloat16 if a == "bf16" else torch.float16
+        hbm = m <= 16
+        out = {"shape": shape, "M": m, "dt": f"{a}x{w}" + ("" if mode == "auto" else f" {mode}")}
         try:
-            # one cell per activation format: MXFP8 (mfma_type 2, FP8-rate instruction) and MXFP4 (6, FP4 x FP4)
-            for act_code, act_name, peak in ((2, "mxfp8", BL.FP8_PEAK_TFLOPS), (6, "mxfp4", BL.FP4_PEAK_TFLOPS)):
-                best = None
-                for nsid in [s for s in gm.solutions() if (s >> 48) & 0xF in (9, 13) and (s >> 32) & 7 == act_code]:
-                    for sk in (1, 2):
-                        if sk > 1 and n * m > 8192 * 512 * 2:
-                            continue   # K split only pays where the plain grid under-fills the chip
-                        cand = (nsid & ~(0xF << 60)) | (sk << 60)
-                        print(f"[bench] cell {shape} M={m} native 0x{cand:x}", file=sys.stderr, flush=True)
-                        rr = gm.time(cand, stream, reps=3, launches=10)
-                        if best is None or rr["us"] < best[1]["us"]:
-                            best = (cand, rr)
-                if best:
-                    cand, rr = best
-                    rr = gm.time(cand, stream, reps=5)
-                    cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": f"bf16 x mxfp4 native, activations -> {act_name} (opt-in)",
-                                  "us": round(rr["us"], 3), "us_min": round(rr["us_min"], 3), "TFLOPS": round(rr["tflops"], 2),
-                                  "bound": "mfma", "peak_TFLOPS": peak, "frac": round(rr["tflops"] / peak, 4),
-                                  "frac_of_fp4_peak": round(rr["tflops"] / BL.FP4_PEAK_TFLOPS, 4),
-                                  "solution": f"0x{cand:x} {_lib.describe_solution(cand)}",
-                                  "note": "both launches (activation quantiser + GEMM) timed"})
-        finally:
-            _lib.lib.petit_enable_native_fp4(0)
-        del wm, gm
-        torch.cuda.empty_cache()
-        try:
-            print(f"[bench] cell {shape} M={m} hipBLASLt", file=sys.stderr, flush=True)
-            hb = BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev)
-            hb.check()
-            rr = hb.time(stream, reps=5)
-            cells.append({"shape": shape, "n": n, "k": k, "M": m, "dtype": "bf16 x bf16 dense, hipBLASLt (comparator)",
-                          "us": round(rr["us"], 3), "us_min": round(rr["us_min"], 3), "TFLOPS": round(rr["tflops"], 2),
-                          "bound": "mfma", "frac": round(rr["tflops"] / BL.BF16_PEAK_TFLOPS, 4),
-                          "solution": "hipblasLtMatmul, HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm, 32 MB workspace",
-                          "launch": rr["launch"]})
-            hb.close()
-            del hb
-        except Exception as exc:  # noqa: BLE001 -- the comparator must never take the bench down
-            notes.append(f"hipBLASLt comparator failed on {shape}: {exc}")
+            if mode == "hipblaslt":
+                weights.clear()
+                torch.cuda.empty_cache()
+                hb = BL.HipblasLtGemm(m, n, k, dtype, dev)
+                hb.check()
+                rr = hb.time(stream, reps=5)
+                hb.close()
+                del hb
+                out.update({"us": round(rr["us"], 2), "us_min": round(rr["us_min"], 2), "TF": round(rr["tflops"], 1),
+                            "frac": round(rr["tflops"] / BL.BF16_PEAK_TFLOPS, 4)})
+            else:
+                if (shape, w) not in weights:
+                    weights.clear()
+                    torch.cuda.empty_cache()
+                    weights[(shape, w)] = BL.Weights(w, n, k, 1280, dev)
+                g = BL.Gemm(weights[(shape, w)], m, dtype, dev)
+                sid = g.resolve(mode_sid[mode])
+                print(f"[bench] cell {shape} M={m} {a}x{w} {mode}: 0x{sid:x} {_lib.describe_solution(sid)}", file=sys.stderr, flush=True)
+                r = g.time(mode_sid[mode], stream, reps=7 if hbm else 5)
+                out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2)})
+                if hbm:
+                    out.update({"GBs": round(r["gbs"]), "frac": round(r["gbs"] / BL.HBM_PEAK_GBS, 4)})
+                else:
+                    out.update({"TF": round(r["tflops"], 1), "frac": round(r["tflops"] / peak[mode], 4)})
+                out["sid"] = f"{sid:x}"
+            cells.append(out)
+        except Exception as exc:  # noqa: BLE001 -- one cell (e.g. the vendor comparator) must never take the table down
+            notes.append(f"{shape} M={m} {a}x{w} {mode} failed: {exc}")
         torch.cuda.empty_cache()
     return {"cells": cells, "cells_notes": notes, "cells_seconds": round(time.time() - t0, 1),
-            "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, "
-                            "median of 5-7 replays; frac = GB/s / 8000 (M <= 16) or TFLOPS / 2500 (M = 512; native: / its MFMA-rate peak)"}
+            "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, median of 5-7 replays; "
+                            "frac = GB/s / 8000 (M <= 16) or TFLOPS / 2500 (M = 512; native_mxfp8 / 5000, native_mxfp4 / 10000, both launches "
+                            "timed); sid = the kernel id the call resolved to (petit_describe_solution names it); hipblaslt = vendor dense "
+                            "bf16 GEMM, HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm"}
 
 
 def host_overhead(step, n_calls: int = 3000) -> dict:
@@ -228,7 +195,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cells", action="store_true", help="headline only (skip the M x shape table)")
     ap.add_argument("--no-host-overhead", action="store_true", help="skip the eager host-cost measurement (profiling runs)")
-    ap.add_argument("--cells-budget-s", type=float, default=150.0)
+    ap.add_argument("--cells-budget-s", type=float, default=170.0)
     ap.add_argument("--cells-child", default="", help=argparse.SUPPRESS)   # internal: run the cell table, append JSON lines to this file
     ap.add_argument("--rotate-mb", type=int, default=1280,
                     help="rotate over at least this many MB of distinct weights; measured on MI355X: per-launch time "

@@ -67,6 +67,13 @@ typedef struct petit_solution_hints {
 /* "Let the library choose": the reference's (unsigned long)-1 sentinel,
  * fp4/gemm_fp4_fp16_grid.cc:46-48. */
 #define PETIT_SOLUTION_AUTO UINT64_MAX
+/* "Let the library choose INSIDE the native-FP4 class" (MXFP4 entry points only; see "Native-FP4 kernels" below): the caller
+ * opts into quantised activations by naming the sentinel -- MXFP8 activations (FP4 x FP8 block-scaled MFMA) or MXFP4
+ * activations (FP4 x FP4).  Needs per-call scratch (petit_gemm_workspace_bytes with the same sentinel); without it the call
+ * returns PETIT_ERROR_KERNEL_SHAPE rather than silently running another accuracy class.  The Python layers spell them
+ * solution_id = -2 / -3. */
+#define PETIT_SOLUTION_AUTO_NATIVE_MXFP8 (UINT64_MAX - 1)
+#define PETIT_SOLUTION_AUTO_NATIVE_MXFP4 (UINT64_MAX - 2)
 
 /*
  * c[m][n] = a[m][k] . dequant(b)[n][k]^T * (*global_scale), f32 accumulate,
@@ -144,6 +151,14 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m,
  *   replaces fp4::ChooseDefaultFp4Fp16Solution  fp4/algo_chooser.cc:64-132 */
 uint64_t petit_gemm_default_solution(const petit_solution_hints *hints,
                                      unsigned m, unsigned n, unsigned k);
+/* The concrete id a call (hints, m, n, k, solution_id, epilogue) that hands over `workspace_bytes` of scratch would RUN:
+ * solution_id may be PETIT_SOLUTION_AUTO, one of the PETIT_SOLUTION_AUTO_NATIVE_* sentinels, or an explicit id (returned
+ * normalised, or 0 when that call would be refused).  petit_gemm_default_solution() answers for "as much scratch as the pick
+ * wants" (what the Python layers provide): possibly an id with a K split (bits 60-63 > 1), which a caller WITHOUT scratch
+ * cannot run -- such a caller (petit_gemm_fp4_fp16_grid / _ex with no registered workspace) gets the kernel this function
+ * names for workspace_bytes = 0.  epilogue may be NULL. */
+uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id,
+                                     const petit_epilogue *epilogue, uint64_t workspace_bytes);
 
 /*
  * Offline repack of checkpoint tensors into the packed layout the GEMM reads
@@ -229,6 +244,9 @@ int petit_convert_reference_mxfp4_scales_host(unsigned *out_scales, const unsign
  *   stream that uses it and calls from any other stream are refused with PETIT_ERROR_BAD_ARGUMENT (explicit ids) or
  *   fall back to a kernel without scratch (AUTO) until petit_set_workspace is called again.  Pass (NULL, 0) to
  *   unregister.  The memory stays owned by the caller.
+ * Alignment: a workspace pointer (per call or registered) must be 256-byte aligned -- the kernels store f32x4 slabs
+ *   and read the quantised activations with 16-byte loads at 256-byte-aligned offsets from it; a misaligned pointer is
+ *   PETIT_ERROR_BAD_ARGUMENT, never a misaligned access.  (hipMalloc and torch allocations are 256 / 512-byte aligned.)
  */
 int petit_gemm_fp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b,
                                 const unsigned *scales, const float *global_scale,
@@ -244,6 +262,10 @@ int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned
  * PETIT_SOLUTION_AUTO (the arch table may name a K-split kernel for the shape).  0: none needed. */
 uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
                                     uint64_t solution_id);
+/* The same with the epilogue of the call taken into account: PETIT_SOLUTION_AUTO resolves differently under
+ * PETIT_ACTIVATION_SILU_MUL (only kernels that hold a gate / up tile pair per wave qualify, none of them K-split). */
+uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
+                                       uint64_t solution_id, const petit_epilogue *epilogue);
 int petit_set_workspace(void *device_ptr, uint64_t bytes);
 /* fp32-slab bytes the split-K nibble of an id implies for (m, n) (kept for round-1 callers; prefer
  * petit_gemm_workspace_bytes, which also covers the native kernels). */

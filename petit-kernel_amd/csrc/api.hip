@@ -75,6 +75,7 @@ bool entry_fits(const SolutionEntry &e, unsigned m, unsigned k) {
 //      BINDS to the first stream that uses it; a call from any other stream is refused (PETIT_ERROR_BAD_ARGUMENT) until
 //      petit_set_workspace is called again -- never a silent race.
 constexpr int kMaxDevices = 64;
+constexpr uintptr_t kWorkspaceAlign = 256;
 struct Workspace {
     std::atomic<void *> ptr{nullptr};
     std::atomic<uint64_t> bytes{0};
@@ -307,6 +308,54 @@ bool native_enabled() {
     return v != 0;
 }
 
+// --- the opt-in native class: PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4 ------------------------------------------------------
+// Default pick inside the native-FP4 class (MXFP4 weights only), for callers that have opted into its accuracy by naming one of
+// the two sentinels: arch table of the class first (tuned_native_gfx950.inc / tune-file rows that name a native kernel), else a
+// small model: rounds the grid needs on the chip x time of one workgroup at the throughput its tile shape sustained on MI355X
+// (bench cells of rounds 2-3: FP4 x FP4 128x256 with two workgroups per CU 3.3 PFLOP/s, 128x128 2.5; FP4 x FP8 64x256 2.3).
+enum : int { kClassExact = 0, kClassNativeFp8 = 8, kClassNativeFp4 = 4 };
+int entry_class(const SolutionEntry &e) {
+    if (!is_native_am(e.shape.am))
+        return kClassExact;
+    return (e.shape.am == kNative32Am && e.shape.pa == 2) ? kClassNativeFp4 : kClassNativeFp8;
+}
+const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, unsigned n, unsigned k, bool need_pairs, bool have_slabs,
+                                      unsigned *splitk_out) {
+    const ArchInfo &arch = arch_info(current_device());
+    const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    const SolutionEntry *best = nullptr;
+    double best_us = 1e30;
+    *splitk_out = 1;
+    for (int i = 0; i < fam.count; ++i) {
+        const SolutionEntry &e = fam.entries[i];
+        const StreamShape &s = e.shape;
+        if (entry_class(e) != klass || !entry_fits(e, m, k) || s.wm != 1 || (need_pairs && !act_ok(e)))
+            continue;
+        const bool k32 = s.am == kNative32Am;
+        const unsigned bm = (k32 ? 32u : 16u) * s.mt, bn = 16u * s.wn * s.nt;
+        const bool two = k32 && klass == kClassNativeFp4 && s.mt * s.nt == 16 && s.d == 2; // Native32Cfg::kMinWavesPerSimd
+        double tflops; // sustained by this tile shape when the chip is full
+        if (k32 && klass == kClassNativeFp4)
+            tflops = two ? 3300.0 : (s.mt * s.nt == 16 ? 2300.0 : 2500.0) + 50.0 * ((s.wk / 4 == 2) + (s.wk % 4 == 2));
+        else if (k32)
+            tflops = 2000.0;
+        else
+            tflops = (s.mt == 4 && s.nt >= 4) ? 2300.0 : 1900.0;
+        const double wgs = (double)((m + bm - 1) / bm) * (double)((n + bn - 1) / bn);
+        const double slots = (double)arch.num_cus * (two ? 2 : 1);
+        for (unsigned sk = 1; sk <= 4 && sk <= nspans; sk *= 2) {
+            if (sk > 1 && (!have_slabs || need_pairs))
+                break;
+            const double rounds = (double)(unsigned long)((wgs * sk + slots - 1) / slots);
+            const double t_wg = 2.0 * bm * bn * ((double)k / sk) / (tflops * 1e6 / slots); // us: the workgroup's share of the chip rate
+            const double us = 6.0 + rounds * t_wg + (sk > 1 ? 1.5 + (double)sk * m * n * 8.0 / 5e6 : 0.0);
+            if (us < best_us)
+                best_us = us, best = &e, *splitk_out = sk;
+        }
+    }
+    return best;
+}
+
 // What solution_id = -1 resolves to for (device, dtypes, act, m, n, k): arch table first, heuristic second; NEVER a
 // native-FP4 kernel (different accuracy class: a tune file that lists one is ignored for AUTO).  The choice is a pure
 // function of its key (the tables are immutable after static init), so every thread keeps a small direct-mapped
@@ -315,33 +364,39 @@ struct AutoChoice {
     const SolutionEntry *entry;
     unsigned splitk;
 };
-AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k) {
+AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k,
+                       int klass = kClassExact) {
     struct Slot {
-        uint64_t key0, key1;
+        uint64_t key0, key1, generation;
         AutoChoice val;
     };
     constexpr int kSlots = 64;
     static thread_local Slot cache[kSlots] = {};
     const uint64_t key0 = ((uint64_t)m << 32) | n;
-    const uint64_t key1 = ((uint64_t)k << 32) | ((uint64_t)(dev & 0xff) << 16) | ((uint64_t)(a_type & 0xf) << 8) |
-                          ((uint64_t)(b_type & 0xf) << 4) | (act ? 2u : 0u) | 1u; // bit 0: slot in use
+    const uint64_t key1 = ((uint64_t)k << 32) | ((uint64_t)(klass & 0xf) << 24) | ((uint64_t)(dev & 0xff) << 16) |
+                          ((uint64_t)(a_type & 0xf) << 8) | ((uint64_t)(b_type & 0xf) << 4) | (act ? 2u : 0u) | 1u; // bit 0: slot in use
+    const uint64_t generation = tuned_generation(); // bumped by petit_tune_* (hal.hip): run-time rows invalidate cached picks
     Slot &slot = cache[(key0 * 0x9E3779B97F4A7C15ull ^ key1 * 0xC2B2AE3D27D4EB4Full) >> 58];
-    if (slot.key0 == key0 && slot.key1 == key1)
+    if (slot.key0 == key0 && slot.key1 == key1 && slot.generation == generation)
         return slot.val;
     AutoChoice c{nullptr, 1};
-    const uint64_t tuned = tuned_solution(dev, a_type, b_type, m, n, k);
+    const uint64_t tuned = tuned_solution(dev, a_type, b_type, m, n, k, klass);
     if (tuned) {
         c.entry = find_entry(fam, tuned);
         c.splitk = solution_splitk(tuned);
-        if (c.entry && (is_native_am(c.entry->shape.am) || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
+        if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
                         (act && (!act_ok(*c.entry) || c.splitk != 1))))
             c.entry = nullptr;
     }
     if (!c.entry)
-        c.entry = heuristic(fam, m, n, k, act, &c.splitk);
-    slot = Slot{key0, key1, c};
+        c.entry = klass == kClassExact ? heuristic(fam, m, n, k, act, &c.splitk) : heuristic_native(fam, klass, m, n, k, act, true, &c.splitk);
+    slot = Slot{key0, key1, generation, c};
     return c;
 }
+int auto_class(uint64_t solution_id) {
+    return solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP8 ? kClassNativeFp8 : solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP4 ? kClassNativeFp4 : kClassExact;
+}
+bool is_auto_id(uint64_t solution_id) { return solution_id == PETIT_SOLUTION_AUTO || auto_class(solution_id) != kClassExact; }
 
 // An explicit id -> table entry.  The element_b nibble is forced to the entry point's format first, as the reference
 // does (gemm_fp4_fp16_grid.cc:79-95): ids enumerated with b_type = FP4_E2M1 (what get_fp4_solutions(m, n, k, a, c)
@@ -371,6 +426,8 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         return kOk; // gemm_fp4_fp16_grid.cc:42-44
     if (!hints || !c || !a || !b || !scales || !global_scale || (!call_ws && call_ws_bytes))
         return kErrBadArgument;
+    if ((uintptr_t)call_ws & (kWorkspaceAlign - 1))
+        return kErrBadArgument; // f32x4 slabs and 16-byte activation loads: the scratch contract is 256-byte alignment (petit_amd.h)
     if (hints->c_type != hints->a_type)
         return kErrKernelShape;
     Family fam;
@@ -386,11 +443,14 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         return kErrProblemShape;
 
     const int dev = current_device();
-    const bool is_auto = solution_id == PETIT_SOLUTION_AUTO;
+    const bool is_auto = is_auto_id(solution_id);
+    const int klass = auto_class(solution_id);
+    if (klass != kClassExact && b_type != kDataTypeMxFp4e2m1)
+        return kErrKernelShape; // the native class exists for MXFP4 weights only (e4m3 group scales are not E8M0 block scales)
     const SolutionEntry *entry = nullptr;
     unsigned splitk = 1;
     if (is_auto) {
-        const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k);
+        const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k, klass);
         entry = ch.entry, splitk = ch.splitk;
         if (!entry)
             return kErrKernelShape;
@@ -425,9 +485,13 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             if (busy && !is_auto)
                 return kErrBadArgument; // the registered workspace is bound to another stream: pass one per call
         }
+        if (!ws && klass != kClassExact && call_ws && call_ws_bytes >= workspace_need(*entry, 1, m, n, k)) {
+            ws = call_ws, splitk = 1; // native default pick with a K split, scratch covers the activations only: the same kernel unsplit
+            need = workspace_need(*entry, 1, m, n, k);
+        }
         if (!ws) {
-            if (!is_auto)
-                return kErrKernelShape; // explicit id that needs scratch nobody provided
+            if (!is_auto || klass != kClassExact)
+                return kErrKernelShape; // explicit id (or the native class) that needs scratch nobody provided
             // AUTO without scratch: the best kernel that needs none (not the K-split pick minus its split: a tiled kernel
             // chosen FOR its split leaves most of the chip idle without it)
             entry = heuristic(fam, m, n, k, act);
@@ -490,19 +554,36 @@ int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned
                      workspace_bytes, stream);
 }
 
-uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
-                                    uint64_t solution_id) {
+// what a call with this epilogue would resolve PETIT_SOLUTION_AUTO to (the SiLU-mul epilogue restricts the candidates)
+static bool epilogue_act(const petit_epilogue *epilogue, bool *ok) {
+    *ok = !epilogue || ((epilogue->activation == PETIT_ACTIVATION_NONE || epilogue->activation == PETIT_ACTIVATION_SILU_MUL) &&
+                        epilogue->reserved == 0);
+    return epilogue && epilogue->activation == PETIT_ACTIVATION_SILU_MUL;
+}
+
+uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
+                                       uint64_t solution_id, const petit_epilogue *epilogue) {
     Family fam;
-    if (!hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) ||
+    bool ok;
+    const bool act = epilogue_act(epilogue, &ok);
+    if (!ok || !hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) ||
         m == 0)
         return 0;
-    if (solution_id == PETIT_SOLUTION_AUTO) {
-        const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, false, m, n, k);
+    if (is_auto_id(solution_id)) {
+        const int klass = auto_class(solution_id);
+        if (klass != kClassExact && hints->b_type != kDataTypeMxFp4e2m1)
+            return 0;
+        const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, klass);
         return ch.entry ? workspace_need(*ch.entry, ch.splitk, m, n, k) : 0;
     }
     const SolutionEntry *e = find_explicit(fam, solution_id);
     const unsigned splitk = solution_splitk(solution_id);
     return e && splitk ? workspace_need(*e, splitk, m, n, k) : 0;
+}
+
+uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
+                                    uint64_t solution_id) {
+    return petit_gemm_workspace_bytes_ex(hints, m, n, k, solution_id, nullptr);
 }
 
 int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
@@ -529,13 +610,39 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
     return 0;
 }
 
-uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k) {
+uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id,
+                                     const petit_epilogue *epilogue, uint64_t workspace_bytes) {
     Family fam;
-    if (!hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) ||
+    bool ok;
+    const bool act = epilogue_act(epilogue, &ok);
+    if (!ok || !hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) ||
         !shape_ok(n, k) || m == 0)
         return 0;
-    const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, false, m, n, k);
+    if (!is_auto_id(solution_id)) {
+        const SolutionEntry *e = find_explicit(fam, solution_id);
+        const unsigned sk = solution_splitk(solution_id);
+        if (!e || !sk || !entry_fits(*e, m, k) || (act && (!act_ok(*e) || sk != 1)) || workspace_need(*e, sk, m, n, k) > workspace_bytes)
+            return 0;
+        return make_solution_id(e->shape, fam.elem_b, entry_mfma(fam, *e), sk);
+    }
+    const int klass = auto_class(solution_id);
+    if (klass != kClassExact && hints->b_type != kDataTypeMxFp4e2m1)
+        return 0;
+    AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, klass);
+    if (ch.entry && workspace_need(*ch.entry, ch.splitk, m, n, k) > workspace_bytes) {
+        // exactly what gemm_impl does when the caller's scratch does not cover the pick
+        if (klass == kClassExact)
+            ch.entry = heuristic(fam, m, n, k, act), ch.splitk = 1;
+        else if (workspace_need(*ch.entry, 1, m, n, k) <= workspace_bytes)
+            ch.splitk = 1;
+        else
+            ch.entry = nullptr;
+    }
     return ch.entry ? make_solution_id(ch.entry->shape, fam.elem_b, entry_mfma(fam, *ch.entry), ch.splitk) : 0;
+}
+
+uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k) {
+    return petit_gemm_resolve_solution(hints, m, n, k, PETIT_SOLUTION_AUTO, nullptr, UINT64_MAX);
 }
 
 int petit_repack_nvfp4_weights(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan,
@@ -598,6 +705,8 @@ int petit_dequant_packed_weights(void *out, const unsigned *b, const unsigned *s
 }
 
 int petit_set_workspace(void *device_ptr, uint64_t bytes) {
+    if ((uintptr_t)device_ptr & (kWorkspaceAlign - 1))
+        return kErrBadArgument;
     Workspace &ws = g_workspace[current_device()];
     ws.bytes.store(0);
     ws.ptr.store(device_ptr);

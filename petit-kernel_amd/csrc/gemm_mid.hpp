@@ -205,9 +205,11 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_mid_kernel(const void *arg
                 // tile kt + 1 complete (this wave's slice), then visible (everybody's): the steps after it that have been
                 // requested (D - 1 of them, fewer at the end of the wave's range) stay in flight
                 constexpr int kYounger = !kLast ? D - 1 : (KS - 2 - T < 0 ? 0 : (KS - 2 - T < D - 1 ? KS - 2 - T : D - 1));
+#ifdef PETIT_AMD_DEBUG_WAITS // debug builds only: $PETIT_AMD_MID_DEBUG=1 drains every step (isolates a wrong wait count)
                 if (arg_dbg & 1u)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else
+#endif
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger * kLoadsPerStep) : "memory");
                 __builtin_amdgcn_s_barrier();
             });

@@ -43,7 +43,16 @@ struct TunedEntry {
     uint64_t solution;   // full id incl. split-K nibble
 };
 
-// 0 when the table has no entry for this problem.
-uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k);
+// 0 when the table has no entry for this problem.  klass 0: the exact kernels (what PETIT_SOLUTION_AUTO may run); 8 / 4: the
+// opt-in native class with MXFP8 / MXFP4 activations (its own table: a row naming a native kernel is never seen by klass 0).
+// Lookup order: rows added at run time (tuned_insert: petit_gemm_tune, $PETIT_AMD_AUTOTUNE), $PETIT_AMD_TUNE_FILE, built-in.
+uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass = 0);
+// class of a solution id: 0 exact, 8 / 4 native with MXFP8 / MXFP4 activations
+int solution_class(uint64_t solution);
+// Add (or replace) a row at run time; thread safe; bumps tuned_generation() so cached default picks are re-derived.
+void tuned_insert(const TunedEntry &e);
+uint64_t tuned_generation();
+// Write every run-time and tune-file row (not the built-in table) in the $PETIT_AMD_TUNE_FILE format; false on I/O error.
+bool tuned_save(const char *path);
 
 } // namespace petit_amd

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -61,9 +62,18 @@ const TunedEntry kBuiltin[] = {
 #include "tuned_gfx950.inc"
     {0, 0, 0, 0, 0, 0, 0} // terminator
 };
+// the opt-in native class (PETIT_SOLUTION_AUTO_NATIVE_*): same columns, ids of kind 9 / 13
+const TunedEntry kBuiltinNative[] = {
+#include "tuned_native_gfx950.inc"
+    {0, 0, 0, 0, 0, 0, 0} // terminator
+};
 
+// rows from $PETIT_AMD_TUNE_FILE (read once) and rows added at run time, newest first; guarded by g_rows_mutex (the lookup
+// runs only when a thread's default-pick cache misses, api.hip choose_auto)
 std::vector<TunedEntry> g_override;
 std::once_flag g_override_once;
+std::mutex g_rows_mutex;
+std::atomic<uint64_t> g_generation{1};
 
 void load_override() {
     const char *path = getenv("PETIT_AMD_TUNE_FILE");
@@ -73,6 +83,7 @@ void load_override() {
     if (!f)
         return;
     char line[256];
+    std::lock_guard<std::mutex> lock(g_rows_mutex);
     while (fgets(line, sizeof(line), f)) {
         if (line[0] == '#' || line[0] == '\n')
             continue;
@@ -80,16 +91,15 @@ void load_override() {
         unsigned long long sol = 0;
         if (sscanf(line, "%d %d %u %u %u %u %llx", &e.a_type, &e.b_type, &e.n, &e.k, &e.m_lo, &e.m_hi, &sol) == 7) {
             e.solution = sol;
-            if (((sol >> 48) & 0xf) == 9)
-                continue; // a native-FP4 kernel is never a default (own accuracy class): the row is ignored
-            g_override.push_back(e);
+            g_override.push_back(e); // (a row naming a native-FP4 kernel lands in the native class by its id: never a plain default)
         }
     }
     fclose(f);
 }
 
-bool matches(const TunedEntry &e, int a_type, int b_type, unsigned m, unsigned n, unsigned k) {
-    return e.a_type == a_type && e.b_type == b_type && e.n == n && e.k == k && m >= e.m_lo && m <= e.m_hi;
+bool matches(const TunedEntry &e, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass) {
+    return e.a_type == a_type && e.b_type == b_type && e.n == n && e.k == k && m >= e.m_lo && m <= e.m_hi &&
+           solution_class(e.solution) == klass;
 }
 
 } // namespace
@@ -101,7 +111,46 @@ const ArchInfo &arch_info(int device) {
     return g_arch[device];
 }
 
-uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k) {
+int solution_class(uint64_t solution) {
+    const unsigned kind = (unsigned)(solution >> 48) & 0xf, mfma = (unsigned)(solution >> 32) & 0x7;
+    if (kind != 9 && kind != 13)
+        return 0;
+    return mfma == 6 ? 4 : 8; // mfma_type nibble: 2 = MXFP8 activations, 6 = MXFP4 (solution.h)
+}
+
+uint64_t tuned_generation() { return g_generation.load(std::memory_order_acquire); }
+
+void tuned_insert(const TunedEntry &e) {
+    std::call_once(g_override_once, load_override);
+    {
+        std::lock_guard<std::mutex> lock(g_rows_mutex);
+        const int klass = solution_class(e.solution);
+        for (size_t i = 0; i < g_override.size();) { // a new row replaces the rows of the same problem and class it overlaps
+            const TunedEntry &o = g_override[i];
+            if (o.a_type == e.a_type && o.b_type == e.b_type && o.n == e.n && o.k == e.k && solution_class(o.solution) == klass &&
+                !(o.m_hi < e.m_lo || o.m_lo > e.m_hi))
+                g_override.erase(g_override.begin() + (long)i);
+            else
+                ++i;
+        }
+        g_override.insert(g_override.begin(), e);
+    }
+    g_generation.fetch_add(1, std::memory_order_acq_rel);
+}
+
+bool tuned_save(const char *path) {
+    std::call_once(g_override_once, load_override);
+    FILE *f = path && *path ? fopen(path, "w") : nullptr;
+    if (!f)
+        return false;
+    fprintf(f, "# a_type b_type n k m_lo m_hi solution   (petit-kernel_amd tune file; $PETIT_AMD_TUNE_FILE)\n");
+    std::lock_guard<std::mutex> lock(g_rows_mutex);
+    for (const TunedEntry &e : g_override)
+        fprintf(f, "%d %d %u %u %u %u %llx\n", e.a_type, e.b_type, e.n, e.k, e.m_lo, e.m_hi, (unsigned long long)e.solution);
+    return fclose(f) == 0;
+}
+
+uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass) {
     // tuned ids are only meaningful on the arch they were measured on
     if (strcmp(arch_info(device).name, "gfx950") != 0)
         return 0;
@@ -112,11 +161,14 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
     if (disabled)
         return 0;
     std::call_once(g_override_once, load_override);
-    for (const TunedEntry &e : g_override)
-        if (matches(e, a_type, b_type, m, n, k))
-            return e.solution;
-    for (const TunedEntry *e = kBuiltin; e->solution; ++e)
-        if (matches(*e, a_type, b_type, m, n, k))
+    {
+        std::lock_guard<std::mutex> lock(g_rows_mutex);
+        for (const TunedEntry &e : g_override)
+            if (matches(e, a_type, b_type, m, n, k, klass))
+                return e.solution;
+    }
+    for (const TunedEntry *e = klass == 0 ? kBuiltin : kBuiltinNative; e->solution; ++e)
+        if (matches(*e, a_type, b_type, m, n, k, klass))
             return e->solution;
     return 0;
 }

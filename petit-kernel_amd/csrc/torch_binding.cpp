@@ -13,6 +13,8 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/library.h>
 
+#include <string>
+
 #include "../../include/petit_amd.h"
 
 namespace {
@@ -99,10 +101,14 @@ at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::
     at::Tensor c = at::empty({size_m, activation ? size_n / 2 : size_n}, A.options());
     const int a_type = A.scalar_type() == at::kBFloat16 ? kCxxBf16 : kCxxFp16;
     const petit_solution_hints hints{a_type, mx ? kCxxMxFp4 : kCxxFp4, a_type, 0};
-    const uint64_t sid = solution_id < 0 ? PETIT_SOLUTION_AUTO : (uint64_t)solution_id;
+    // ids are 64-bit patterns whose top nibble is the K split: a split of 8..15 sets bit 63, and the schema's `int` is a
+    // signed int64 -- such an id arrives as its two's-complement value (petit_kernel/compiled.py maps it) and is
+    // reinterpreted here; -1 is PETIT_SOLUTION_AUTO (all ones), as in the reference (fp4.cc:189-191: solution_id < 0)
+    const uint64_t sid = (uint64_t)solution_id;
     const petit_epilogue epi{bias.has_value() ? bias->data_ptr() : nullptr, (int32_t)activation, 0};
     // per-call scratch from the caching allocator (stream-ordered, capture-safe): K-split slabs / native-FP4 activations
-    const uint64_t ws_bytes = petit_gemm_workspace_bytes(&hints, (unsigned)size_m, (unsigned)size_n, (unsigned)size_k, sid);
+    const uint64_t ws_bytes = petit_gemm_workspace_bytes_ex(&hints, (unsigned)size_m, (unsigned)size_n, (unsigned)size_k, sid,
+                                                            (bias.has_value() || activation) ? &epi : nullptr);
     at::Tensor ws;
     if (ws_bytes)
         ws = at::empty({(int64_t)ws_bytes}, A.options().dtype(at::kByte));
@@ -111,7 +117,7 @@ at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::
                       (const float *)global_scale.data_ptr(), (unsigned)size_m, (unsigned)size_n, (unsigned)size_k, &hints, sid,
                       (bias.has_value() || activation) ? &epi : nullptr, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, stream_of(A));
     TORCH_CHECK(rc != PETIT_ERROR_PROBLEM_SHAPE, "Incompatible problem shape (m=", size_m, ", n=", size_n, ", k=", size_k, ")");
-    TORCH_CHECK(rc != PETIT_ERROR_KERNEL_SHAPE, "No kernel implementation for solution_id=", solution_id, ".");
+    TORCH_CHECK(rc != PETIT_ERROR_KERNEL_SHAPE, "No kernel implementation for solution_id=", sid == PETIT_SOLUTION_AUTO ? "-1" : std::to_string(sid), ".");
     TORCH_CHECK(rc == PETIT_OK, mx ? "mul_mxfp4_a16: " : "mul_nvfp4_a16: ", petit_error_string(rc));
     return c;
 }

@@ -13,7 +13,7 @@ import enum
 import torch
 
 from . import compiled, offline, ops
-from .ops import PetitSolutionHints
+from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
 
 # operator layer: the compiled torch.library binding when it is built and loads (csrc/torch_binding.cpp), else the
 # ctypes layer; both are thin shims over the same C ABI (there is no other compute path)
@@ -77,4 +77,7 @@ __all__ = [
     "get_fp4_solutions",
     "DataType",
     "PetitSolutionHints",
+    "SOLUTION_AUTO",
+    "SOLUTION_AUTO_NATIVE_MXFP8",
+    "SOLUTION_AUTO_NATIVE_MXFP4",
 ]

@@ -18,6 +18,8 @@ PETIT_ERROR_KERNEL_SHAPE = 2
 PETIT_ERROR_LAUNCH = 3
 PETIT_ERROR_BAD_ARGUMENT = 4
 PETIT_SOLUTION_AUTO = 0xFFFFFFFFFFFFFFFF
+PETIT_SOLUTION_AUTO_NATIVE_MXFP8 = PETIT_SOLUTION_AUTO - 1   # Python surface: solution_id = -2
+PETIT_SOLUTION_AUTO_NATIVE_MXFP4 = PETIT_SOLUTION_AUTO - 2   # Python surface: solution_id = -3
 
 # C++ DataType numbering of the reference (quantization/types.h:4-13)
 CXX_DTYPE_FP4_E2M1 = 3
@@ -49,6 +51,8 @@ _SIGNATURES = {
     "petit_gemm_mxfp4_fp16_grid_ws": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
                                       [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue), C.c_void_p, C.c_uint64, C.c_void_p]),
     "petit_gemm_workspace_bytes": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64]),
+    "petit_gemm_workspace_bytes_ex": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Epilogue)]),
+    "petit_gemm_resolve_solution": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Epilogue), C.c_uint64]),
     "petit_gemm_fp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
                                  [C.POINTER(SolutionHints), C.c_uint64, C.c_void_p]),
     "petit_gemm_mxfp4_fp16_grid": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +

@@ -51,6 +51,20 @@ def _act(activation) -> int:
     return _ACT[activation]
 
 
+def _sid(solution_id: int) -> int:
+    """Python id -> the signed 64-bit value the op schema carries (`int` = int64).  Ids are unsigned 64-bit patterns with
+    the K split in bits 60-63, so a split of 8..15 does not fit a signed int64 as such: it crosses as its two's-complement
+    value and the binding reinterprets it.  Any negative id means "library default" (reference: fp4.cc:189-191)."""
+    solution_id = int(solution_id)
+    if solution_id in (-2, -3):     # default pick inside the opt-in native class (ops.SOLUTION_AUTO_NATIVE_*): UINT64_MAX - 1 / - 2
+        return solution_id
+    if solution_id < 0:
+        return -1
+    if solution_id >= 1 << 64:
+        raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
+    return solution_id - (1 << 64) if solution_id >= 1 << 63 else solution_id
+
+
 def repack_nvfp4(b_q_weight, size_n, size_k):
     return torch.ops.petit_kernel.repack_nvfp4(b_q_weight, size_n, size_k)
 
@@ -64,8 +78,8 @@ def process_mxfp4_scales(scales, size_n, size_k):
 
 
 def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None):
-    return torch.ops.petit_kernel.mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, _act(activation))
+    return torch.ops.petit_kernel.mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))
 
 
 def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None):
-    return torch.ops.petit_kernel.mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, _act(activation))
+    return torch.ops.petit_kernel.mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))

@@ -144,16 +144,33 @@ def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torc
 
 _ACTIVATIONS = {None: 0, "none": 0, "silu_mul": 1}   # PETIT_ACTIVATION_* (include/petit_amd.h)
 
+# solution_id of the Python surface: any negative value = "library default" as in the reference (fp4.cc:189-191), with two
+# values reserved for the default pick INSIDE the opt-in native-FP4 class (MXFP4 weights only; petit_amd.h)
+SOLUTION_AUTO = -1
+SOLUTION_AUTO_NATIVE_MXFP8 = -2
+SOLUTION_AUTO_NATIVE_MXFP4 = -3
+
+
+def _c_solution_id(solution_id: int) -> int:
+    solution_id = int(solution_id)
+    if solution_id == SOLUTION_AUTO_NATIVE_MXFP8:
+        return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8
+    if solution_id == SOLUTION_AUTO_NATIVE_MXFP4:
+        return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4
+    return _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else solution_id
+
 _ws_need_cache = {}
 
 
-def _workspace_need(a_type: int, b_type: int, m: int, n: int, k: int, sid: int) -> int:
-    """petit_gemm_workspace_bytes, memoised per problem (a pure function of its arguments)."""
-    key = (a_type, b_type, m, n, k, sid)
+def _workspace_need(a_type: int, b_type: int, m: int, n: int, k: int, sid: int, act: int = 0) -> int:
+    """petit_gemm_workspace_bytes_ex, memoised per problem (a pure function of its arguments; of the epilogue only the
+    activation matters)."""
+    key = (a_type, b_type, m, n, k, sid, act)
     need = _ws_need_cache.get(key)
     if need is None:
         hints = _CHints(a_type, b_type, a_type, 0)
-        need = int(_lib.lib.petit_gemm_workspace_bytes(C.byref(hints), m, n, k, C.c_uint64(sid)))
+        epi = _lib.Epilogue(None, act, 0)
+        need = int(_lib.lib.petit_gemm_workspace_bytes_ex(C.byref(hints), m, n, k, C.c_uint64(sid), C.byref(epi) if act else None))
         if len(_ws_need_cache) > 4096:
             _ws_need_cache.clear()
         _ws_need_cache[key] = need
@@ -180,7 +197,7 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
     # require_high_precision: the reference turns it on for arch <= gfx90a when
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
-    sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
+    sid = _c_solution_id(solution_id)
     epi = None
     if bias is not None or act:
         # fused epilogue (include/petit_amd.h, petit_epilogue): c = round16(act(acc * gs + bias[n]))
@@ -188,14 +205,15 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
             _check(bias.is_cuda and bias.device == A.device and bias.dtype == A.dtype and bias.is_contiguous() and
                    bias.numel() == size_n, "bias must be a contiguous [size_n] tensor of A's dtype on A's device")
         epi = _lib.Epilogue(bias.data_ptr() if bias is not None else None, act, 0)
-    # Scratch for kernels that need it (cross-workgroup K split, native-FP4 path): per call, from torch's
-    # stream-ordered caching allocator -- safe with several streams and under graph capture.  A workspace
-    # registered with set_workspace() is honoured instead (round-1 behaviour) when one is set for this device.
-    ws, ws_bytes = None, 0
-    if A.device.index not in _workspace_keepalive:
-        ws_bytes = _workspace_need(a_type, b_type, size_m, size_n, size_k, sid)
-        if ws_bytes:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
+    # Scratch for kernels that need it (cross-workgroup K split, native-FP4 path): ALWAYS per call, from torch's
+    # stream-ordered caching allocator -- safe with several streams and under graph capture, and the same rule as the
+    # compiled binding (a workspace registered with set_workspace() serves raw C-ABI callers only: it binds to one
+    # stream, and a call from a second stream -- e.g. the side stream torch.cuda.graph captures on after an eager
+    # warm-up -- would otherwise drop silently to a slower no-scratch kernel).
+    ws = None
+    ws_bytes = _workspace_need(a_type, b_type, size_m, size_n, size_k, sid, act)
+    if ws_bytes:
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device)
     fn = _lib.lib.petit_gemm_fp4_fp16_grid_ws if kind == "nv" else _lib.lib.petit_gemm_mxfp4_fp16_grid_ws
     with torch.cuda.device(A.device):
         err = fn(_ptr(c), _ptr(A), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k,
@@ -272,9 +290,20 @@ def native_workspace_bytes(size_m: int, size_k: int) -> int:
 
 def workspace_bytes(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, solution_id: int = -1) -> int:
     """Scratch bytes the call would use (split-K slabs, native-FP4 activations); mul_*_a16 allocates them itself."""
-    sid = _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else int(solution_id)
+    sid = _c_solution_id(solution_id)
     ch = _c_hints(hints)
     return int(_lib.lib.petit_gemm_workspace_bytes(C.byref(ch), size_m, size_n, size_k, C.c_uint64(sid)))
+
+
+def resolve_solution(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, solution_id: int = -1, activation=None,
+                     workspace_bytes: int = 1 << 62) -> int:
+    """The concrete kernel id a call with these arguments runs (petit_gemm_resolve_solution): solution_id may be -1, -2 / -3
+    (default pick inside the native class) or an explicit id; 0 when the call would be refused."""
+    ch = _c_hints(hints)
+    act = _ACTIVATIONS[activation]
+    epi = _lib.Epilogue(None, act, 0)
+    return int(_lib.lib.petit_gemm_resolve_solution(C.byref(ch), size_m, size_n, size_k, C.c_uint64(_c_solution_id(solution_id)),
+                                                    C.byref(epi) if act else None, C.c_uint64(workspace_bytes)))
 
 
 def dequant_packed(B: torch.Tensor, s: torch.Tensor, size_n: int, size_k: int, kind: str = "nvfp4", dtype=torch.float32,
@@ -301,8 +330,9 @@ _workspace_keepalive = {}
 def set_workspace(buf) -> None:
     """Register (or with None, unregister) a device scratch tensor for kernels that need one
     (split-K slabs, quantised activations of the native path).  The tensor is kept alive here.
-    Optional: without a registered workspace mul_*_a16 allocates the scratch per call.  A registered
-    workspace serves ONE stream (include/petit_amd.h "Scratch memory")."""
+    Only raw C-ABI callers of the entry points WITHOUT a workspace argument use it (petit_gemm_*_grid, _ex):
+    mul_*_a16 of both Python layers always allocates its scratch per call.  A registered workspace serves
+    ONE stream (include/petit_amd.h "Scratch memory")."""
     if buf is None:
         with torch.cuda.device(torch.cuda.current_device()):
             _lib.lib.petit_set_workspace(None, 0)

@@ -258,7 +258,7 @@ def test_arch_table_rows_and_tune_file_override(tmp_path):
     for at, bt, n, k, lo, hi, sol in rows:
         at, bt, n, k, lo, hi, sol = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16)
         hints = _lib.SolutionHints(at, bt, at, 0)
-        assert (sol >> 32) & 7 != 2, "a native-FP4 kernel must never be a default"
+        assert (sol >> 48) & 0xF not in (9, 13), "a native-FP4 kernel must never be a default"   # (as tools/make_tuned_inc.py)
         for m in {lo, min(hi, lo + 3)}:
             assert _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k) == sol, (at, bt, n, k, m, hex(sol))
             assert "unknown" not in _lib.describe_solution(sol)
@@ -293,11 +293,12 @@ def test_tune_file_native_row_is_ignored_for_auto(tmp_path):
         assert _lib.lib.petit_gemm_get_solutions(C.byref(hints), m, n, k, ids, C.byref(cnt)) == 0
     finally:
         _lib.lib.petit_enable_native_fp4(0)
-    native = next(i for i in ids if (i >> 48) & 0xF == 9)
-    tune = tmp_path / "tune.txt"
-    tune.write_text(f"{at} {bt} {n} {k} {m} {m} {native:x}\n")
-    got = _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune), "PETIT_AMD_NATIVE_FP4": "1"}, at, bt, m, n, k)
-    assert got == want, (hex(got), hex(want))
+    for kind in (9, 13):   # the 16x16x128 and the 32x32x64 native kernels
+        native = next(i for i in ids if (i >> 48) & 0xF == kind)
+        tune = tmp_path / f"tune{kind}.txt"
+        tune.write_text(f"{at} {bt} {n} {k} {m} {m} {native:x}\n")
+        got = _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune), "PETIT_AMD_NATIVE_FP4": "1"}, at, bt, m, n, k)
+        assert got == want, (kind, hex(got), hex(want))
 
 
 def test_workspace_bytes_query():

@@ -32,6 +32,30 @@ LLAMA70B = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "
             "sq4096": (4096, 4096), "sq8192": (8192, 8192)}
 
 
+# The cell table of bench.py (the rest of BASELINE.json's metric: "TFLOPS + achieved HBM GB/s, M in {1, 8, 16, 512}, Llama-70B
+# shapes" + configs[2] M = 4, configs[3] fp16 x MXFP4, configs[4] native FP4 / hipBLASLt, and the reference benchmark's own default
+# dtype, fp16 x NVFP4, tools/benchmarks/matmul.py:92-127), in the order bench.py measures it.  tests/test_gpu_parity.py::
+# test_bench_cells_parity iterates the SAME list, so every (shape, M, dtype, mode) that is timed is also checked against the oracle.
+#   mode: "auto" = solution_id -1; "native_mxfp8" / "native_mxfp4" = the opt-in native class through its own default pick;
+#   "hipblaslt" = the vendor's dense 16-bit GEMM on a dense weight of the same shape (comparator, no parity to check)
+SHAPE_ORDER = ("qkv", "o", "gate_up", "down")
+
+
+def bench_cell_plan() -> list:
+    plan = []
+    # the bandwidth-bound cells of every shape first (a decode cell timed right after seconds of 1.3 kW compute reads 5-10 % slow)
+    for shape in SHAPE_ORDER:
+        plan += [dict(shape=shape, M=m, a="bf16", w="nv", mode="auto") for m in (1, 4, 8, 16)]
+        plan += [dict(shape=shape, M=16, a="fp16", w="nv", mode="auto")]
+        plan += [dict(shape=shape, M=m, a="fp16", w="mx", mode="auto") for m in (1, 16)]
+    for shape in SHAPE_ORDER:
+        plan += [dict(shape=shape, M=512, a="bf16", w="nv", mode="auto"), dict(shape=shape, M=512, a="fp16", w="nv", mode="auto"),
+                 dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"),
+                 dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
+                 dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt")]
+    return plan
+
+
 def alg_bytes(m: int, n: int, k: int, group: int) -> int:
     """every operand counted once."""
     return n * k // 2 + n * k // group + 2 * m * k + 2 * m * n + 4
@@ -108,6 +132,11 @@ class Gemm:
 
     def default_solution(self) -> int:
         return int(_lib.lib.petit_gemm_default_solution(C.byref(self.hints), self.m, self.w.n, self.w.k))
+
+    def resolve(self, sid: int, workspace_bytes: int = 1 << 62) -> int:
+        """the concrete kernel a call with `sid` (an AUTO sentinel or an explicit id) runs, given that much scratch"""
+        return int(_lib.lib.petit_gemm_resolve_solution(C.byref(self.hints), self.m, self.w.n, self.w.k, C.c_uint64(sid), None,
+                                                        C.c_uint64(workspace_bytes)))
 
     def solutions(self) -> list:
         count = C.c_uint(0)
