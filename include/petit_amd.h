@@ -283,6 +283,48 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
 int petit_enable_native_fp4(int enable);
 uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);
 
+/*
+ * Tune-and-persist (replaces the reference's `bench_matmul -algo tune`, tools/benchmarks/matmul/main.cc:269-325, which
+ * enumerates and times every solution on the user's device but leaves the winning id for the user to carry around).
+ *
+ * petit_gemm_tune() runs every kernel of the class that fits (m, n, k) and `workspace_bytes`, with the K splits its kind
+ * supports: first CHECKS the candidate's output against the class's reference kernel (|c - ref| <= tolerance * max(1, |ref|),
+ * every element), then times it with HIP events on `stream` (launches rotate over the weight copies so that the 256 MB
+ * Infinity Cache cannot serve them), and returns the fastest id and its microseconds per launch.  With persist != 0 the
+ * winner becomes what PETIT_SOLUTION_AUTO (klass 0) or PETIT_SOLUTION_AUTO_NATIVE_* (klass 8 / 4) picks for (dtypes, n, k)
+ * and the M bucket of m (or [m_lo, m_hi] when given) from now on, in this process; petit_tune_save() writes all such rows in
+ * the $PETIT_AMD_TUNE_FILE format, which a later process loads on its first call.  `c` is scratch output (overwritten).
+ * The call synchronises `stream`, allocates device memory and must not run inside a graph capture
+ * (PETIT_ERROR_BAD_ARGUMENT).  Returns PETIT_ERROR_KERNEL_SHAPE when no candidate passed.
+ * $PETIT_AMD_AUTOTUNE=1 does the same implicitly: the first PETIT_SOLUTION_AUTO call of a (dtypes, n, k, M bucket) that no table
+ * knows is tuned in place (own scratch, own clones of the caller's weights) before it runs, and $PETIT_AMD_TUNE_FILE, when
+ * set, is rewritten with the new row.
+ */
+typedef struct petit_tune_params {
+    uint32_t struct_bytes;       /* sizeof(petit_tune_params) */
+    int32_t klass;               /* 0: the exact kernels; 8 / 4: the native class, MXFP8 / MXFP4 activations (MXFP4 weights only) */
+    uint32_t n_copies;           /* >= 1 packed (weights, scales) pairs to rotate over */
+    uint32_t launches;           /* launches per timed sample; 0 = sized so that a sample lasts ~0.3 ms */
+    const void *const *b;        /* n_copies device pointers: packed weights */
+    const void *const *scales;   /* n_copies device pointers: packed scales */
+    uint64_t rotate_bytes;       /* n_copies == 1 only: clone the pair on the device until the rotation covers this many bytes
+                                    (0 = time on the single copy: cache-resident numbers for small shapes) */
+    uint32_t samples;            /* timed samples per candidate, median reported; 0 = 5 */
+    float tolerance;             /* 0 = 2e-2 */
+    int32_t persist;             /* insert the winner into the run-time arch table */
+    uint32_t m_lo, m_hi;         /* M range of the persisted row; 0, 0 = the bucket of m (1, 2, 3-4, 5-8, ..., 129-256, 257+) */
+    uint32_t reserved;
+} petit_tune_params;
+int petit_gemm_tune(unsigned *c, const unsigned *a, const float *global_scale, unsigned m, unsigned n, unsigned k,
+                    const petit_solution_hints *hints, const petit_tune_params *params, void *workspace, uint64_t workspace_bytes,
+                    void *stream, uint64_t *best_solution, float *best_us);
+/* Add one row by hand (e.g. from a sweep done elsewhere): solution must be a kernel id of this build. */
+int petit_tune_insert(const petit_solution_hints *hints, unsigned n, unsigned k, unsigned m_lo, unsigned m_hi, uint64_t solution);
+/* Write the run-time rows and the rows loaded from $PETIT_AMD_TUNE_FILE to `path` (same format). */
+int petit_tune_save(const char *path);
+/* Bumped whenever a row is added: callers that memoise petit_gemm_workspace_bytes / default picks key their cache on it. */
+uint64_t petit_tune_generation(void);
+
 /* Human-readable text for a return code. */
 const char *petit_error_string(int code);
 /* Layout tag of the packed tensors ("petit-cdna4/1") and library version. */

@@ -414,6 +414,52 @@ const SolutionEntry *find_explicit(const Family &fam, uint64_t id) {
     return e;
 }
 
+} // namespace
+
+// Candidates of a tuning run (tune.hip): every kernel of the class that can run (m, n, k) within `max_ws` bytes of scratch,
+// with the K splits its kind supports.  Also the reference kernel the outputs are compared with (first element): the
+// direct-path streaming kernel for the exact class (no staging, no K split: the simplest code path), the first 16x16x128
+// (MXFP8) / 32x32x64 (MXFP4) native kernel for the native classes.
+int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, unsigned k, uint64_t max_ws, uint64_t *ids, uint64_t *needs,
+                    int cap) {
+    Family fam;
+    if (!family_for(a_type, b_type, &fam) || !shape_ok(n, k) || m == 0 || (klass != kClassExact && b_type != kDataTypeMxFp4e2m1))
+        return 0;
+    const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    int count = 0;
+    auto push = [&](const SolutionEntry &e, unsigned sk, bool front) {
+        const uint64_t need = workspace_need(e, sk, m, n, k);
+        if (need > max_ws || count >= cap)
+            return;
+        const uint64_t id = make_solution_id(e.shape, fam.elem_b, entry_mfma(fam, e), sk);
+        if (front && count) {
+            ids[count] = ids[0], needs[count] = needs[0];
+            ids[0] = id, needs[0] = need;
+        } else {
+            ids[count] = id, needs[count] = need;
+        }
+        ++count;
+    };
+    bool have_ref = false;
+    for (int i = 0; i < fam.count; ++i) {
+        const SolutionEntry &e = fam.entries[i];
+        const StreamShape &s = e.shape;
+        if (entry_class(e) != klass || !entry_fits(e, m, k))
+            continue;
+        const bool is_ref = !have_ref && (klass == kClassExact ? (s.am == 0 && s.wm == 1 && s.pa == 1) : true);
+        have_ref |= is_ref;
+        push(e, 1, is_ref);
+        // K splits: the large-M kernels and the direct-path streaming kernel take any split; the staged / decode / shared-tile
+        // kernels none (one workgroup column walks all of K)
+        const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am == 0 && s.wm == 1);
+        if (!splittable)
+            continue;
+        for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)
+            push(e, sk, false);
+    }
+    return count;
+}
+
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
               const float *global_scale, unsigned m, unsigned n, unsigned k,
               const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
@@ -450,6 +496,9 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     const SolutionEntry *entry = nullptr;
     unsigned splitk = 1;
     if (is_auto) {
+        // $PETIT_AMD_AUTOTUNE=1: a problem no table knows is tuned once, here, before its first real launch (tune.hip)
+        if (klass == kClassExact && !act && autotune_enabled() && tuned_solution(dev, hints->a_type, b_type, m, n, k, kClassExact) == 0)
+            autotune_on_first_sight(b_type, c, a, b, scales, global_scale, m, n, k, hints->a_type, stream);
         const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k, klass);
         entry = ch.entry, splitk = ch.splitk;
         if (!entry)
@@ -504,7 +553,6 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     return entry->launch(args, splitk, (hipStream_t)stream);
 }
 
-} // namespace
 } // namespace petit_amd
 
 using namespace petit_amd;

@@ -46,6 +46,42 @@ struct GemmArgs {
 };
 enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u };
 
+// api.hip: the dispatcher behind every GEMM entry point (solution_id: explicit id or one of the AUTO sentinels)
+} // namespace petit_amd
+struct petit_solution_hints;
+struct petit_epilogue;
+namespace petit_amd {
+int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,
+              unsigned n, unsigned k, const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue, void *call_ws,
+              uint64_t call_ws_bytes, void *stream);
+int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, unsigned k, uint64_t max_ws, uint64_t *ids, uint64_t *needs,
+                    int cap);
+
+// tune.hip
+struct TuneRequest {
+    void *c;                 // [m][n] output buffer the candidates may overwrite
+    const void *a;           // [m][k] activations
+    const void *const *b;    // n_copies packed weight pointers
+    const void *const *s;    // n_copies packed scale pointers
+    unsigned n_copies;
+    const float *gs;
+    unsigned m, n, k;
+    int a_type, b_type, klass;   // klass 0 exact, 8 / 4 native with MXFP8 / MXFP4 activations
+    void *ws;
+    uint64_t ws_bytes;
+    bool own_workspace;      // allocate scratch for the largest candidate instead of using ws
+    void *stream;
+    unsigned launches, samples;
+    float tolerance;
+    bool persist;
+    unsigned m_lo, m_hi;
+    size_t rotate_bytes;     // n_copies == 1: clone the weights until the rotation covers this many bytes
+};
+int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us);
+bool autotune_enabled();
+void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *gs, unsigned m,
+                             unsigned n, unsigned k, int a_type, void *stream);
+
 // repack.hip
 int repack_weights(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);
 int repack_nvscales(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);

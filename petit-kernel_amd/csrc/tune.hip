@@ -1,0 +1,291 @@
+// tune.hip -- tune-and-persist inside the library: time every kernel that can run a problem ON THE USER'S DEVICE, check each
+// candidate's output, record the winner in the run-time arch table (hal.hip) and optionally in a tune file.
+//
+// Replaces the reference's `bench_matmul -algo tune` (tools/benchmarks/matmul/main.cc:269-325: enumerate GemmGetSolutions,
+// time each with hipEvents, print the best id) -- there a benchmark binary whose result the user has to carry back into
+// his call sites by hand, here a library entry point (petit_gemm_tune), its Python wrapper (petit_kernel.tune) and an opt-in
+// "tune on first sight" mode ($PETIT_AMD_AUTOTUNE=1) that feed PETIT_SOLUTION_AUTO directly; rows persist through
+// petit_tune_save / $PETIT_AMD_TUNE_FILE and are loaded on the first call of a later process (hal.hip load_override).
+//
+// Method (the one tools/benchlib.py uses, in C): every launch of a timed sample reads a DIFFERENT copy of the weights so that
+// the 256 MB Infinity Cache cannot serve them (the caller passes the copies, or the tuner clones the caller's one copy
+// into a rotation of its own); one untimed sample first; median of `samples` hipEvent-timed samples; a candidate whose first
+// sample is 1.5x behind the leader is dropped early.  A candidate is only timed after its output matched the class's
+// reference kernel (api.hip tune_candidates) element by element: a kernel that miscomputes at this shape is never ranked.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/petit_amd.h"
+#include "hal.h"
+#include "petit_internal.h"
+
+namespace petit_amd {
+namespace {
+
+// |x - ref| <= tol * max(1, |ref|) for every element, NaN / inf must agree; *bad counts violations
+__global__ __launch_bounds__(256) void compare_outputs_kernel(const unsigned short *x, const unsigned short *ref, size_t count, int is_bf16,
+                                                              float tol, unsigned *bad) {
+    unsigned local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        float a, b;
+        if (is_bf16) {
+            const unsigned ua = (unsigned)x[i] << 16, ub = (unsigned)ref[i] << 16;
+            a = __builtin_bit_cast(float, ua), b = __builtin_bit_cast(float, ub);
+        } else {
+            const unsigned short ha = x[i], hb = ref[i];
+            a = (float)__builtin_bit_cast(_Float16, ha), b = (float)__builtin_bit_cast(_Float16, hb);
+        }
+        const bool fa = __builtin_isfinite(a), fb = __builtin_isfinite(b);
+        if (fa != fb || (fa && !(fabsf(a - b) <= tol * fmaxf(1.0f, fabsf(b)))))
+            ++local;
+    }
+    if (local)
+        atomicAdd(bad, local);
+}
+
+struct DeviceBuffers { // everything the tuner allocated itself; freed on every exit path
+    std::vector<void *> ptrs;
+    void *alloc(size_t bytes) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        ptrs.push_back(p);
+        return p;
+    }
+    ~DeviceBuffers() {
+        for (void *p : ptrs)
+            (void)hipFree(p);
+    }
+};
+
+bool env_on(const char *name) {
+    const char *e = getenv(name);
+    return e && *e && *e != '0';
+}
+
+} // namespace
+
+void tune_bucket(unsigned m, uint64_t solution, unsigned *m_lo, unsigned *m_hi) {
+    // the M buckets of the built-in table (tools/make_tuned_inc.py): 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, 65-128, 129-256, 257+
+    unsigned lo = 1, hi = 1;
+    while (hi < m && hi < 256)
+        lo = hi + 1, hi *= 2;
+    if (m > 256)
+        lo = 257, hi = 1u << 20;
+    // a kernel that stages at most AM activation rows cannot serve a bucket that reaches past AM: the row covers m alone
+    static const int kRowsOfCode[16] = {0, 1, 2, 4, 1, 1, 2, 4, 0, 0, 8, 16, 0, 0, 2, 4};
+    const int rows = kRowsOfCode[(solution >> 48) & 0xf];
+    if (rows && (unsigned)rows < hi)
+        lo = hi = m;
+    *m_lo = lo, *m_hi = hi;
+}
+
+int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us) {
+    if (!rq.c || !rq.a || !rq.gs || !rq.b || !rq.s || rq.n_copies == 0 || rq.m == 0)
+        return kErrBadArgument;
+    hipStream_t stream = (hipStream_t)rq.stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+        return kErrBadArgument; // tuning synchronises and allocates: never inside a graph capture
+    constexpr int kCap = 1024;
+    std::vector<uint64_t> ids(kCap), needs(kCap);
+    const uint64_t max_ws = rq.own_workspace ? (uint64_t)1 << 30 : rq.ws_bytes;
+    const int count = tune_candidates(rq.a_type, rq.b_type, rq.klass, rq.m, rq.n, rq.k, max_ws, ids.data(), needs.data(), kCap);
+    if (count == 0)
+        return kErrKernelShape;
+
+    DeviceBuffers mem;
+    const size_t out_elems = (size_t)rq.m * rq.n;
+    unsigned short *c_ref = (unsigned short *)mem.alloc(out_elems * 2);
+    unsigned *bad = (unsigned *)mem.alloc(sizeof(unsigned));
+    if (!c_ref || !bad)
+        return kErrLaunch;
+    void *ws = rq.ws;
+    uint64_t ws_bytes = rq.ws_bytes;
+    if (rq.own_workspace) {
+        uint64_t want = 0;
+        for (int i = 0; i < count; ++i)
+            want = std::max(want, needs[i]);
+        ws = want ? mem.alloc(want) : nullptr;
+        ws_bytes = ws ? want : 0;
+    }
+    // the rotation: the caller's copies, or clones of his single copy up to rotate_bytes (all-or-nothing per clone)
+    std::vector<const void *> wb(rq.b, rq.b + rq.n_copies), ws_(rq.s, rq.s + rq.n_copies);
+    const size_t w_bytes = (size_t)rq.n * rq.k / 2, s_bytes = (size_t)rq.n * rq.k / (rq.b_type == kDataTypeMxFp4e2m1 ? 32 : 16);
+    if (rq.n_copies == 1 && rq.rotate_bytes > w_bytes + s_bytes) {
+        const size_t clones = std::min<size_t>(63, rq.rotate_bytes / (w_bytes + s_bytes));
+        for (size_t i = 0; i < clones; ++i) {
+            void *w2 = mem.alloc(w_bytes), *s2 = w2 ? mem.alloc(s_bytes) : nullptr;
+            if (!w2 || !s2)
+                break;
+            if (hipMemcpyAsync(w2, rq.b[0], w_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                hipMemcpyAsync(s2, rq.s[0], s_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                break;
+            wb.push_back(w2), ws_.push_back(s2);
+        }
+    }
+    const size_t copies = wb.size();
+
+    const petit_solution_hints hints{rq.a_type, rq.b_type, rq.a_type, 0};
+    auto run = [&](uint64_t id, void *out, size_t copy) {
+        return gemm_impl(rq.b_type, (unsigned *)out, (const unsigned *)rq.a, (const unsigned *)wb[copy % copies],
+                         (const unsigned *)ws_[copy % copies], rq.gs, rq.m, rq.n, rq.k, &hints, id, nullptr, ws, ws_bytes, rq.stream);
+    };
+    // reference output: candidate 0 (tune_candidates puts the class's reference kernel first)
+    if (run(ids[0], c_ref, 0) != kOk || hipStreamSynchronize(stream) != hipSuccess)
+        return kErrLaunch;
+
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        return kErrLaunch;
+    const float tol = rq.tolerance > 0.f ? rq.tolerance : 2e-2f;
+    const unsigned samples = rq.samples ? rq.samples : 5;
+    uint64_t best = 0;
+    float best_t = 1e30f;
+    int rc = kOk;
+    size_t rot = 0;
+    for (int i = 0; i < count && rc == kOk; ++i) {
+        const uint64_t id = ids[i];
+        // 1. the output check
+        if (hipMemsetAsync(bad, 0, sizeof(unsigned), stream) != hipSuccess || run(id, rq.c, 0) != kOk)
+            continue; // (a candidate the launcher refuses -- e.g. a grid limit -- is simply not ranked)
+        hipLaunchKernelGGL(compare_outputs_kernel, dim3(512), dim3(256), 0, stream, (const unsigned short *)rq.c, c_ref, out_elems,
+                           rq.a_type == kDataTypeBf16 ? 1 : 0, tol, bad);
+        unsigned nbad = 1;
+        if (hipMemcpyAsync(&nbad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess) {
+            rc = kErrLaunch;
+            break;
+        }
+        if (nbad)
+            continue;
+        // 2. timing: one untimed sample sizes the batch, then `samples` timed ones
+        unsigned launches = rq.launches;
+        std::vector<float> us;
+        for (unsigned sm = 0; sm <= samples; ++sm) {
+            const unsigned batch = launches ? launches : 4;
+            (void)hipEventRecord(e0, stream);
+            for (unsigned l = 0; l < batch; ++l)
+                if (run(id, rq.c, rot++) != kOk)
+                    rc = kErrLaunch;
+            (void)hipEventRecord(e1, stream);
+            if (hipEventSynchronize(e1) != hipSuccess)
+                rc = kErrLaunch;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const float per = ms * 1e3f / (float)batch;
+            if (rc != kOk)
+                break;
+            if (sm == 0) { // untimed: choose the batch so that a sample lasts ~0.3 ms (at least 4, at most 256 launches)
+                if (!launches)
+                    launches = (unsigned)std::min(256.0f, std::max(4.0f, 300.0f / std::max(per, 0.5f)));
+                continue;
+            }
+            us.push_back(per);
+            if (sm == 1 && per > 1.5f * best_t)
+                break; // hopeless: not worth four more samples
+        }
+        if (rc != kOk || us.empty())
+            continue;
+        std::sort(us.begin(), us.end());
+        const float med = us[us.size() / 2];
+        if (us.size() >= samples / 2 + 1 && med < best_t)
+            best_t = med, best = id;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != kOk)
+        return rc;
+    if (!best)
+        return kErrKernelShape;
+    if (best_solution)
+        *best_solution = best;
+    if (best_us)
+        *best_us = best_t;
+    if (rq.persist) {
+        TunedEntry e{};
+        e.a_type = rq.a_type, e.b_type = rq.b_type, e.n = rq.n, e.k = rq.k, e.solution = best;
+        if (rq.m_lo && rq.m_hi >= rq.m_lo)
+            e.m_lo = rq.m_lo, e.m_hi = rq.m_hi;
+        else
+            tune_bucket(rq.m, best, &e.m_lo, &e.m_hi);
+        tuned_insert(e);
+    }
+    return kOk;
+}
+
+// $PETIT_AMD_AUTOTUNE=1: PETIT_SOLUTION_AUTO tunes a problem whose (dtypes, N, K, M bucket) no table knows, once, on first
+// sight, with the caller's own buffers (the output is overwritten by candidates and then by the real call), clones of the
+// caller's weights for the rotation and scratch of its own; the row lands in the run-time table and, when
+// $PETIT_AMD_TUNE_FILE is set, in that file (rewritten with all run-time rows) for the next process.
+bool autotune_enabled() {
+    static const bool on = env_on("PETIT_AMD_AUTOTUNE");
+    return on;
+}
+void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *gs, unsigned m,
+                             unsigned n, unsigned k, int a_type, void *stream) {
+    const void *bp = b, *sp = scales;
+    TuneRequest rq{};
+    rq.c = c, rq.a = a, rq.b = &bp, rq.s = &sp, rq.n_copies = 1, rq.gs = gs;
+    rq.m = m, rq.n = n, rq.k = k, rq.a_type = a_type, rq.b_type = b_type, rq.klass = 0;
+    rq.own_workspace = true, rq.stream = stream, rq.persist = true;
+    rq.rotate_bytes = (size_t)384 << 20; // past the 256 MB Infinity Cache
+    uint64_t best = 0;
+    float us = 0.f;
+    if (tune_problem(rq, &best, &us) != kOk) {
+        // remember the failure as a row naming the heuristic's own pick would; simplest: nothing -- the next call tries again
+        return;
+    }
+    const char *path = getenv("PETIT_AMD_TUNE_FILE");
+    if (path && *path)
+        (void)tuned_save(path);
+}
+
+} // namespace petit_amd
+
+using namespace petit_amd;
+
+extern "C" {
+
+int petit_gemm_tune(unsigned *c, const unsigned *a, const float *global_scale, unsigned m, unsigned n, unsigned k,
+                    const petit_solution_hints *hints, const petit_tune_params *params, void *workspace, uint64_t workspace_bytes,
+                    void *stream, uint64_t *best_solution, float *best_us) {
+    if (!hints || !params || params->struct_bytes != sizeof(petit_tune_params) || hints->c_type != hints->a_type)
+        return kErrBadArgument;
+    if (params->klass != 0 && params->klass != 8 && params->klass != 4)
+        return kErrBadArgument;
+    if (((uintptr_t)workspace & 255) || (!workspace && workspace_bytes))
+        return kErrBadArgument;
+    TuneRequest rq{};
+    rq.c = c, rq.a = a, rq.b = params->b, rq.s = params->scales, rq.n_copies = params->n_copies, rq.gs = global_scale;
+    rq.m = m, rq.n = n, rq.k = k, rq.a_type = hints->a_type, rq.b_type = hints->b_type, rq.klass = params->klass;
+    rq.ws = workspace, rq.ws_bytes = workspace_bytes, rq.own_workspace = false, rq.stream = stream;
+    rq.launches = params->launches, rq.samples = params->samples, rq.tolerance = params->tolerance;
+    rq.persist = params->persist != 0, rq.m_lo = params->m_lo, rq.m_hi = params->m_hi;
+    rq.rotate_bytes = params->rotate_bytes;
+    return tune_problem(rq, best_solution, best_us);
+}
+
+int petit_tune_insert(const petit_solution_hints *hints, unsigned n, unsigned k, unsigned m_lo, unsigned m_hi, uint64_t solution) {
+    if (!hints || m_lo == 0 || m_hi < m_lo || n == 0 || k == 0 || solution == 0 || solution == PETIT_SOLUTION_AUTO)
+        return kErrBadArgument;
+    char buf[8];
+    if (petit_describe_solution(solution, buf, sizeof(buf)) != kOk)
+        return kErrKernelShape; // not a kernel of this build
+    TunedEntry e{};
+    e.a_type = hints->a_type, e.b_type = hints->b_type, e.n = n, e.k = k, e.m_lo = m_lo, e.m_hi = m_hi, e.solution = solution;
+    tuned_insert(e);
+    return kOk;
+}
+
+int petit_tune_save(const char *path) { return tuned_save(path) ? kOk : kErrBadArgument; }
+
+uint64_t petit_tune_generation(void) { return tuned_generation(); }
+
+} // extern "C"

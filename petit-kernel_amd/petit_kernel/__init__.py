@@ -12,7 +12,8 @@ import enum
 
 import torch
 
-from . import compiled, offline, ops
+from . import compiled, offline, ops, tuning
+from .tuning import tune, tune_tensors
 from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
 
 # operator layer: the compiled torch.library binding when it is built and loads (csrc/torch_binding.cpp), else the
@@ -77,6 +78,8 @@ __all__ = [
     "get_fp4_solutions",
     "DataType",
     "PetitSolutionHints",
+    "tune",
+    "tune_tensors",
     "SOLUTION_AUTO",
     "SOLUTION_AUTO_NATIVE_MXFP8",
     "SOLUTION_AUTO_NATIVE_MXFP4",

@@ -40,6 +40,14 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("activation", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TuneParams(C.Structure):
+    """petit_tune_params (include/petit_amd.h)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("klass", C.c_int32), ("n_copies", C.c_uint32), ("launches", C.c_uint32),
+                ("b", C.POINTER(C.c_void_p)), ("scales", C.POINTER(C.c_void_p)), ("rotate_bytes", C.c_uint64),
+                ("samples", C.c_uint32), ("tolerance", C.c_float), ("persist", C.c_int32), ("m_lo", C.c_uint32), ("m_hi", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
 # every symbol include/petit_amd.h declares, with its signature
 _SIGNATURES = {
     "petit_gemm_fp4_fp16_grid_ex": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 +
@@ -74,6 +82,11 @@ _SIGNATURES = {
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
     "petit_enable_native_fp4": (C.c_int, [C.c_int]),
     "petit_native_workspace_bytes": (C.c_uint64, [C.c_uint, C.c_uint]),
+    "petit_gemm_tune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(SolutionHints),
+                                  C.POINTER(TuneParams), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+    "petit_tune_insert": (C.c_int, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint64]),
+    "petit_tune_save": (C.c_int, [C.c_char_p]),
+    "petit_tune_generation": (C.c_uint64, []),
     "petit_error_string": (C.c_char_p, [C.c_int]),
     "petit_layout_tag": (C.c_char_p, []),
     "petit_version": (C.c_char_p, []),

@@ -165,7 +165,7 @@ _ws_need_cache = {}
 def _workspace_need(a_type: int, b_type: int, m: int, n: int, k: int, sid: int, act: int = 0) -> int:
     """petit_gemm_workspace_bytes_ex, memoised per problem (a pure function of its arguments; of the epilogue only the
     activation matters)."""
-    key = (a_type, b_type, m, n, k, sid, act)
+    key = (a_type, b_type, m, n, k, sid, act, _lib.lib.petit_tune_generation())   # (a tuned row may change what AUTO needs)
     need = _ws_need_cache.get(key)
     if need is None:
         hints = _CHints(a_type, b_type, a_type, 0)

@@ -1035,11 +1035,15 @@ def check_native_sampled(P, c, a_bits, act_code, tag):
     """A native-FP4 kernel's output on FullSizeProblem P's sampled columns: (1) exact semantics against the oracle run on the
     CPU-quantised activations (usual 1e-2 bound), (2) the class's stated end-to-end tolerance against the unquantised oracle
     (act_code 2 = MXFP8 activations: 2e-2 * sum|a||w| + 1e-2; 6 = MXFP4: 0.12 * sum|a||w| + 1e-2)."""
-    a_f32 = to_f32(a_bits, True)
-    a_q = quantize_act_mxfp8(a_f32) if act_code == 2 else quantize_act_mxfp4(a_f32)
-    _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, P.dq, P.gs)
-    _, full = O.gemm_ref(a_bits, True, P.dq, P.gs)
-    sum_abs = (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs
+    cache = P.__dict__.setdefault("_native_refs", {})
+    key = (act_code, a_bits.shape, a_bits.tobytes()[:64], int(a_bits.view(np.uint16).sum()))   # (the references depend on the activations only)
+    if key not in cache:
+        a_f32 = to_f32(a_bits, True)
+        a_q = quantize_act_mxfp8(a_f32) if act_code == 2 else quantize_act_mxfp4(a_f32)
+        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, P.dq, P.gs)
+        _, full = O.gemm_ref(a_bits, True, P.dq, P.gs)
+        cache[key] = (exact, full, (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs)
+    exact, full, sum_abs = cache[key]
     got = to_f32(bits(c[:, torch.from_numpy(P.rows).to(DEV)]), True).astype(np.float64)
     err = np.abs(got - exact)
     assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)).all(), f"{tag}: exact-semantics max err {err.max()}"
@@ -1436,3 +1440,92 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
     finally:
         pk.ops.set_workspace(None)
         pk.ops.enable_native_fp4(False)
+
+
+# --- tune-and-persist inside the library (csrc/tune.hip; the reference's `bench_matmul -algo tune`, main.cc:269-325) ------
+
+def test_in_library_tune_picks_checks_and_persists(pk, tmp_path):
+    """petit_kernel.tune_tensors on shapes no table knows: the winner is an enumerated kernel (possibly with a K split), it
+    becomes what solution_id = -1 resolves to for its M bucket at once, the AUTO output still matches the oracle, the class
+    sentinel -3 follows a native-class tune, and the saved file reproduces the pick in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    from petit_kernel import _lib
+    for kind, m, n, k in (("nv", 16, 2048, 4096), ("nv", 200, 256, 16384), ("mx", 40, 1024, 2048)):
+        a_bits, q, s, gs = random_problem(kind, m, n, k, 4400 + m, True)
+        a = from_bits(a_bits, torch.bfloat16).to(DEV)
+        qd = torch.from_numpy(q).to(DEV)
+        gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+        b = pk.repack_nvfp4(qd.view(torch.int32), n, k)
+        sp = (pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k) if kind == "nv"
+              else pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k))
+        h = pk.PetitSolutionHints()
+        h.a_type = h.c_type = torch.bfloat16
+        h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+        sid, us = pk.tune_tensors(a, (b, sp), gsd, m, n, k, kind="nvfp4" if kind == "nv" else "mxfp4", rotate_mb=96)
+        assert us > 0 and (sid & ~(0xF << 60)) | (1 << 60) in pk.ops.get_fp4_solutions(h, m, n, k)
+        assert pk.ops.resolve_solution(h, m, n, k, -1) == sid
+        c = (pk.mul_nvfp4_a16 if kind == "nv" else pk.mul_mxfp4_a16)(a, b, sp, gsd, m, n, k, -1)
+        check_gemm(bits(c), oracle_ref(kind, a_bits, True, q, s, gs), True, oracle_sum_abs(kind, a_bits, True, q, s, gs))
+        if kind == "mx":
+            nsid, nus = pk.tune_tensors(a, (b, sp), gsd, m, n, k, kind="mxfp4", klass="native_mxfp4", rotate_mb=96)
+            assert (nsid >> 48) & 0xF == 13 and (nsid >> 32) & 7 == 6 and nus > 0
+            assert pk.ops.resolve_solution(h, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP4) == nsid
+            assert pk.ops.resolve_solution(h, m, n, k, -1) == sid          # the exact class is untouched by it
+    path = tmp_path / "tuned.txt"
+    pk.tuning.save(path)
+    rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
+    assert len(rows) >= 4
+    at, bt, n, k, lo, hi, sol = rows[-1]     # the oldest row: the first problem tuned above
+    code = ("import sys, ctypes as C; sys.path.insert(0, r'%s'); from petit_kernel import _lib; h = _lib.SolutionHints(%s, %s, %s, 0); "
+            "print('%%x' %% _lib.lib.petit_gemm_default_solution(C.byref(h), %s, %s, %s))" % (ROOT / "petit-kernel_amd", at, bt, at, lo, n, k))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PETIT_AMD_TUNE_FILE=str(path)), capture_output=True, text=True, check=True)
+    assert out.stdout.strip().splitlines()[-1] == sol
+
+
+def test_autotune_on_first_sight(pk, tmp_path):
+    """$PETIT_AMD_AUTOTUNE=1 + $PETIT_AMD_TUNE_FILE: the first solution_id = -1 call of an unseen shape tunes it in place (own
+    scratch, clones of the caller's weights), returns the right result, and leaves a row in the file; the second call and a
+    graph capture run without tuning again."""
+    import os
+    import subprocess
+    import sys
+    path = tmp_path / "auto_tuned.txt"
+    code = r"""
+import sys
+sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s')
+import numpy as np, torch
+import petit_kernel as pk
+from petit_kernel import _lib
+m, n, k = 12, 1536, 3072
+g = torch.Generator().manual_seed(5)
+a = torch.randn((m, k), generator=g).bfloat16().cuda()
+q = torch.randint(0, 256, (n, k // 2), generator=g, dtype=torch.uint8).cuda()
+s = (torch.rand((n, k // 16), generator=g) * 3.5 + 0.25).to(torch.float8_e4m3fn).cuda()
+gs = torch.tensor([1.0], device='cuda')
+b = pk.repack_nvfp4(q.view(torch.int32), n, k); sp = pk.process_nvfp4_scales(s, n, k)
+h = pk.PetitSolutionHints(); h.a_type = h.c_type = torch.bfloat16; h.b_type = pk.DataType.float4_e2m1
+g0 = _lib.lib.petit_tune_generation()
+c1 = pk.mul_nvfp4_a16(a, b, sp, gs, m, n, k, -1)
+assert _lib.lib.petit_tune_generation() == g0 + 1, 'first sight must tune'
+picked = pk.ops.resolve_solution(h, m, n, k, -1)
+c2 = pk.mul_nvfp4_a16(a, b, sp, gs, m, n, k, picked)
+assert torch.equal(c1.view(torch.int16), c2.view(torch.int16))
+dense = pk.ops.dequant_packed(b, sp, n, k, 'nvfp4')
+ref = a.float() @ dense.t()
+assert torch.allclose(c1.float(), ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item())
+pk.mul_nvfp4_a16(a, b, sp, gs, m, n, k, -1)
+assert _lib.lib.petit_tune_generation() == g0 + 1, 'second call must not tune again'
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr):
+    pk.mul_nvfp4_a16(a, b, sp, gs, 9, n, k, -1)      # same M bucket (9..16): served by the row, nothing to tune under capture
+gr.replay(); torch.cuda.synchronize()
+print('%%x' %% picked)
+""" % (ROOT / "petit-kernel_amd", ROOT)
+    env = dict(os.environ, PETIT_AMD_AUTOTUNE="1", PETIT_AMD_TUNE_FILE=str(path))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    picked = out.stdout.strip().splitlines()[-1]
+    rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
+    assert ["5", "3", "1536", "3072"] == rows[0][:4] and rows[0][6] == picked

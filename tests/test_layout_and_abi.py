@@ -404,3 +404,95 @@ def test_heuristic_stays_close_to_the_measured_best():
     assert m, out
     median, p90, worst = (float(x) for x in m.groups())
     assert median <= 1.03 and p90 <= 1.2 and worst <= 1.7, out
+
+
+# --- tune-and-persist plumbing (csrc/tune.hip, hal.hip): everything that needs no GPU ----------------
+
+def test_run_time_tune_rows_round_trip(tmp_path):
+    """petit_tune_insert -> what PETIT_SOLUTION_AUTO resolves to changes at once (the per-thread pick cache is keyed on the
+    table's generation); petit_tune_save writes the $PETIT_AMD_TUNE_FILE format; a fresh process that names the file picks the
+    same kernel on its first call; the memoised workspace query follows the new pick."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, r'%s')
+from petit_kernel import _lib
+L = _lib.lib
+at, bt, m, n, k = _lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, 128, 3072, 5120       # a shape no built-in row names
+h = _lib.SolutionHints(at, bt, at, 0)
+before = L.petit_gemm_default_solution(C.byref(h), m, n, k)
+cnt = C.c_uint(0); L.petit_gemm_get_solutions(C.byref(h), m, n, k, None, C.byref(cnt))
+ids = (C.c_uint64 * cnt.value)(); L.petit_gemm_get_solutions(C.byref(h), m, n, k, ids, C.byref(cnt))
+tiled = next(i for i in ids if (i >> 48) & 0xF == 8 and i != before)
+pick = (tiled & ~(0xF << 60)) | (4 << 60)                                                  # with a K split of 4: needs scratch
+g0 = L.petit_tune_generation()
+assert L.petit_gemm_workspace_bytes(C.byref(h), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO)) == L.petit_gemm_workspace_bytes(C.byref(h), m, n, k, C.c_uint64(before))
+assert L.petit_tune_insert(C.byref(h), n, k, 65, 128, C.c_uint64(pick)) == 0
+assert L.petit_tune_generation() > g0
+assert L.petit_gemm_default_solution(C.byref(h), m, n, k) == pick
+assert L.petit_gemm_default_solution(C.byref(h), 64, n, k) != pick                         # outside the row's M range
+assert L.petit_gemm_workspace_bytes(C.byref(h), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO)) == 4 * m * n * 4
+# a caller without scratch gets the best kernel that needs none -- and resolve_solution says which
+no_ws = L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO), None, C.c_uint64(0))
+assert no_ws and (no_ws >> 60) == 1 and no_ws != pick
+assert L.petit_tune_insert(C.byref(h), n, k, 65, 128, C.c_uint64(0x1234)) == _lib.PETIT_ERROR_KERNEL_SHAPE   # not a kernel id
+assert L.petit_tune_insert(C.byref(h), n, k, 0, 128, C.c_uint64(pick)) == _lib.PETIT_ERROR_BAD_ARGUMENT
+assert L.petit_tune_save(sys.argv[1].encode()) == 0
+print('%%x' %% pick)
+""" % (ROOT / "petit-kernel_amd")
+    path = tmp_path / "tuned.txt"
+    env = dict(os.environ, PETIT_AMD_TUNE_FILE="")
+    out = subprocess.run([sys.executable, "-c", code, str(path)], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    pick = int(out.stdout.strip().splitlines()[-1], 16)
+    rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
+    assert rows == [["5", "3", "3072", "5120", "65", "128", f"{pick:x}"]]
+    from petit_kernel import _lib
+    assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(path)}, _lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, 100, 3072, 5120) == pick
+
+
+def test_native_class_default_picks():
+    """solution_id -2 / -3 (PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4): the pick comes from the class's own table, else its own
+    model; it is always a native kernel of the requested activation format, exists for MXFP4 weights only, needs scratch, and
+    PETIT_SOLUTION_AUTO itself never resolves to one."""
+    from petit_kernel import _lib
+    L = _lib.lib
+    rows = re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}",
+                      (ROOT / "petit-kernel_amd/csrc/tuned_native_gfx950.inc").read_text())
+    assert rows
+    for at, bt, n, k, lo, hi, sol in rows:
+        at, bt, n, k, lo, sol = int(at), int(bt), int(n), int(k), int(lo), int(sol, 16)
+        assert bt == _lib.CXX_DTYPE_MXFP4_E2M1 and (sol >> 48) & 0xF in (9, 13)
+        h = _lib.SolutionHints(at, bt, at, 0)
+        sentinel = _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4 if (sol >> 32) & 7 == 6 else _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8
+        assert L.petit_gemm_resolve_solution(C.byref(h), lo, n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == sol
+        assert "unknown" not in _lib.describe_solution(sol)
+    for at in (_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP16):
+        h = _lib.SolutionHints(at, _lib.CXX_DTYPE_MXFP4_E2M1, at, 0)
+        for (m, n, k) in [(512, 5120, 13824), (64, 96, 512), (2048, 57344, 8192), (300, 4096, 768), (17, 32, 256)]:   # unseen shapes, every span size
+            exact = L.petit_gemm_default_solution(C.byref(h), m, n, k)
+            assert exact and (exact >> 48) & 0xF not in (9, 13)
+            for sentinel, code in ((_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, 2), (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 6)):
+                sid = L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40))
+                assert sid and (sid >> 48) & 0xF in (9, 13) and (sid >> 32) & 7 == code, (m, n, k, hex(sid))
+                need = L.petit_gemm_workspace_bytes(C.byref(h), m, n, k, C.c_uint64(sentinel))
+                assert need >= m * k // 2
+                # scratch that covers the quantised activations but no K-split slabs: the same kernel, unsplit
+                small = L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), None, C.c_uint64(_lib.lib.petit_native_workspace_bytes(m, k)))
+                assert small and (small >> 60) == 1 and (small ^ sid) & ~(0xF << 60) == 0
+                assert L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), None, C.c_uint64(0)) == 0
+        hn = _lib.SolutionHints(at, _lib.CXX_DTYPE_FP4_E2M1, at, 0)
+        assert L.petit_gemm_resolve_solution(C.byref(hn), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), None, C.c_uint64(1 << 40)) == 0
+        assert L.petit_gemm_workspace_bytes(C.byref(hn), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)) == 0
+
+
+def test_tune_params_struct_matches_the_header():
+    from petit_kernel import _lib
+    text = (ROOT / "include/petit_amd.h").read_text()
+    body = text[text.index("typedef struct petit_tune_params {"):text.index("} petit_tune_params;")]
+    fields = re.findall(r"^\s+(?:const void \*const \*|u?int(?:32|64)_t |float )\s*(\w+(?:, \w+)*);", body, flags=re.M)
+    names = [n.strip() for f in fields for n in f.split(",")]
+    assert names == [f[0] for f in _lib.TuneParams._fields_]
+    assert C.sizeof(_lib.TuneParams) == 64
