@@ -284,6 +284,39 @@ int petit_enable_native_fp4(int enable);
 uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);
 
 /*
+ * The native class as a PIPELINE (no counterpart in the reference).  petit_gemm_mxfp4_fp16_grid_ws with a native id runs two
+ * launches per GEMM (activation quantiser, then the block-scaled-MFMA kernel).  Two hand-over points remove the quantiser:
+ *   a_format   8 / 4: `a` is not the 16-bit matrix but activations ALREADY quantised to MXFP8 / MXFP4 for (m, k), produced by
+ *              petit_quantize_activations() (once, for any number of GEMMs that share the input: q / k / v, gate / up) or by
+ *              a producer GEMM's epilogue (next item).  The bytes are opaque ("petit-qact/1": k-tile-major, the 32x32x64
+ *              kernels' operand order); petit_quantized_activation_bytes() sizes them.  0: `a` is the 16-bit [m][k] matrix.
+ *   out_format 8 / 4, with epilogue->activation = PETIT_ACTIVATION_SILU_MUL: `c` receives silu(y_gate) * y_up QUANTISED for the
+ *              next GEMM (m, k' = n / 2) -- petit_quantized_activation_bytes(m, n / 2, out_format) bytes -- instead of the
+ *              16-bit [m][n/2] matrix: gate_up -> SiLU-mul -> down of a gated MLP in two launches.  Needs n % 512 == 0 and a
+ *              kernel with 128 x 256 workgroup tiles (the sentinels pick one).  Quantised from the f32 result with the
+ *              quantiser's own rule (E8M0 scale from the block maximum of 32 columns).
+ * solution_id: PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4 (must match a_format when given) or an explicit native kernel id;
+ * with a_format or out_format set only the 32x32x64 kernels qualify (PETIT_ERROR_KERNEL_SHAPE otherwise).  hints->a_type
+ * names the 16-bit type of the matrix input / output and of the bias.  workspace: what petit_gemm_native_workspace_bytes()
+ * says for the same arguments (with a_format set: only the slabs of a K split; often 0).
+ */
+typedef struct petit_native_args {
+    uint32_t struct_bytes; /* sizeof(petit_native_args) */
+    int32_t a_format;      /* 0, 8 (MXFP8) or 4 (MXFP4) */
+    int32_t out_format;    /* 0, 8 or 4 */
+    int32_t reserved;      /* 0 */
+} petit_native_args;
+int petit_gemm_mxfp4_native(void *c, const void *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,
+                            unsigned n, unsigned k, const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
+                            const petit_native_args *native, void *workspace, uint64_t workspace_bytes, void *stream);
+uint64_t petit_gemm_native_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id,
+                                           const petit_epilogue *epilogue, const petit_native_args *native);
+/* 16-bit activations [m][k] (a_type PETIT_DTYPE_BF16 / _FP16) -> "petit-qact/1" bytes of `format` (8 / 4) in qa; k % 256 == 0,
+ * both pointers 16-byte aligned. */
+uint64_t petit_quantized_activation_bytes(unsigned m, unsigned k, int format);
+int petit_quantize_activations(void *qa, const void *a, unsigned m, unsigned k, int a_type, int format, void *stream);
+
+/*
  * Tune-and-persist (replaces the reference's `bench_matmul -algo tune`, tools/benchmarks/matmul/main.cc:269-325, which
  * enumerates and times every solution on the user's device but leaves the winning id for the user to carry around).
  *

@@ -16,7 +16,7 @@
 #include <cstring>
 
 #include "../../include/petit_amd.h"
-#include "gemm_native.hpp"
+#include "gemm_native32.hpp"
 #include "gemm_stream.hpp"
 #include "hal.h"
 #include "layout.h"
@@ -95,9 +95,9 @@ uint64_t splitk_bytes(unsigned splitk, unsigned m, unsigned n) {
     return splitk > 1 ? (uint64_t)splitk * m * n * sizeof(float) : 0;
 }
 // bytes of scratch a (kernel, split) needs for (m, n, k): [native: quantised activations, 256-B aligned][slabs]
-uint64_t workspace_need(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k) {
+uint64_t workspace_need(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k, bool have_qa = false) {
     const uint64_t slabs = splitk_bytes(splitk, m, n);
-    if (is_native_am(e.shape.am)) // (sized for MXFP8 activations; the MXFP4 form needs less)
+    if (is_native_am(e.shape.am) && !have_qa) // (sized for MXFP8 activations; the MXFP4 form needs less)
         return slabs ? native_ws_aligned(m, k) + slabs : native_ws_bytes(m, k);
     return slabs;
 }
@@ -319,8 +319,19 @@ int entry_class(const SolutionEntry &e) {
         return kClassExact;
     return (e.shape.am == kNative32Am && e.shape.pa == 2) ? kClassNativeFp4 : kClassNativeFp8;
 }
+// restrictions the native pipeline puts on the kernel: bit 0 = pre-quantised activations (the 32x32x64 kernels' layout: kind 13
+// only), bit 1 = quantising SiLU-mul epilogue (kind 13 with 128 x 256 workgroup tiles, four waves, no K split)
+enum : unsigned { kNeedK32 = 1u, kNeedQuantOut = 2u };
+bool entry_allows(const SolutionEntry &e, unsigned restrict_) {
+    const StreamShape &s = e.shape;
+    if ((restrict_ & (kNeedK32 | kNeedQuantOut)) && s.am != kNative32Am)
+        return false;
+    if ((restrict_ & kNeedQuantOut) && !(s.nt == 4 && s.wn == 4 && s.wm == 1))
+        return false;
+    return true;
+}
 const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, unsigned n, unsigned k, bool need_pairs, bool have_slabs,
-                                      unsigned *splitk_out) {
+                                      unsigned *splitk_out, unsigned restrict_ = 0) {
     const ArchInfo &arch = arch_info(current_device());
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
     const SolutionEntry *best = nullptr;
@@ -329,7 +340,7 @@ const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, 
     for (int i = 0; i < fam.count; ++i) {
         const SolutionEntry &e = fam.entries[i];
         const StreamShape &s = e.shape;
-        if (entry_class(e) != klass || !entry_fits(e, m, k) || s.wm != 1 || (need_pairs && !act_ok(e)))
+        if (entry_class(e) != klass || !entry_fits(e, m, k) || s.wm != 1 || (need_pairs && !act_ok(e)) || !entry_allows(e, restrict_))
             continue;
         const bool k32 = s.am == kNative32Am;
         const unsigned bm = (k32 ? 32u : 16u) * s.mt, bn = 16u * s.wn * s.nt;
@@ -344,7 +355,7 @@ const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, 
         const double wgs = (double)((m + bm - 1) / bm) * (double)((n + bn - 1) / bn);
         const double slots = (double)arch.num_cus * (two ? 2 : 1);
         for (unsigned sk = 1; sk <= 4 && sk <= nspans; sk *= 2) {
-            if (sk > 1 && (!have_slabs || need_pairs))
+            if (sk > 1 && (!have_slabs || need_pairs || (restrict_ & kNeedQuantOut)))
                 break;
             const double rounds = (double)(unsigned long)((wgs * sk + slots - 1) / slots);
             const double t_wg = 2.0 * bm * bn * ((double)k / sk) / (tflops * 1e6 / slots); // us: the workgroup's share of the chip rate
@@ -365,7 +376,7 @@ struct AutoChoice {
     unsigned splitk;
 };
 AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k,
-                       int klass = kClassExact) {
+                       int klass = kClassExact, unsigned restrict_ = 0) {
     struct Slot {
         uint64_t key0, key1, generation;
         AutoChoice val;
@@ -373,7 +384,7 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
     constexpr int kSlots = 64;
     static thread_local Slot cache[kSlots] = {};
     const uint64_t key0 = ((uint64_t)m << 32) | n;
-    const uint64_t key1 = ((uint64_t)k << 32) | ((uint64_t)(klass & 0xf) << 24) | ((uint64_t)(dev & 0xff) << 16) |
+    const uint64_t key1 = ((uint64_t)k << 32) | ((uint64_t)(restrict_ & 0x3) << 28) | ((uint64_t)(klass & 0xf) << 24) | ((uint64_t)(dev & 0xff) << 16) |
                           ((uint64_t)(a_type & 0xf) << 8) | ((uint64_t)(b_type & 0xf) << 4) | (act ? 2u : 0u) | 1u; // bit 0: slot in use
     const uint64_t generation = tuned_generation(); // bumped by petit_tune_* (hal.hip): run-time rows invalidate cached picks
     Slot &slot = cache[(key0 * 0x9E3779B97F4A7C15ull ^ key1 * 0xC2B2AE3D27D4EB4Full) >> 58];
@@ -385,11 +396,12 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
         c.entry = find_entry(fam, tuned);
         c.splitk = solution_splitk(tuned);
         if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
-                        (act && (!act_ok(*c.entry) || c.splitk != 1))))
+                        (act && (!act_ok(*c.entry) || c.splitk != 1)) || !entry_allows(*c.entry, restrict_)))
             c.entry = nullptr;
     }
     if (!c.entry)
-        c.entry = klass == kClassExact ? heuristic(fam, m, n, k, act, &c.splitk) : heuristic_native(fam, klass, m, n, k, act, true, &c.splitk);
+        c.entry = klass == kClassExact ? heuristic(fam, m, n, k, act, &c.splitk)
+                                       : heuristic_native(fam, klass, m, n, k, act, true, &c.splitk, restrict_);
     slot = Slot{key0, key1, generation, c};
     return c;
 }
@@ -463,11 +475,14 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
               const float *global_scale, unsigned m, unsigned n, unsigned k,
               const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
-              void *call_ws, uint64_t call_ws_bytes, void *stream) {
+              void *call_ws, uint64_t call_ws_bytes, void *stream, const NativeIo *io) {
     if (epilogue && ((epilogue->activation != PETIT_ACTIVATION_NONE && epilogue->activation != PETIT_ACTIVATION_SILU_MUL) ||
                      epilogue->reserved != 0))
         return kErrBadArgument; // reject what a newer caller might ask for
     const bool act = epilogue && epilogue->activation == PETIT_ACTIVATION_SILU_MUL;
+    const unsigned a_format = io ? io->a_format : 0u, out_format = io ? io->out_format : 0u;
+    if ((a_format != 0 && a_format != 8 && a_format != 4) || (out_format != 0 && out_format != 8 && out_format != 4))
+        return kErrBadArgument;
     if (m == 0 || n == 0 || k == 0)
         return kOk; // gemm_fp4_fp16_grid.cc:42-44
     if (!hints || !c || !a || !b || !scales || !global_scale || (!call_ws && call_ws_bytes))
@@ -487,19 +502,33 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     // 32-bit buffer offsets inside one n-tile row / activation block
     if ((uint64_t)k * 16 * 4 * 2 >= (1ull << 31) || (uint64_t)k * 64 * 4 >= (1ull << 31))
         return kErrProblemShape;
+    // the native pipeline: pre-quantised activations / quantised SiLU-mul output (MXFP4 weights, 32x32x64 kernels only)
+    const unsigned restrict_ = (a_format ? kNeedK32 : 0u) | (out_format ? kNeedQuantOut : 0u);
+    if (restrict_ && b_type != kDataTypeMxFp4e2m1)
+        return kErrKernelShape;
+    if (out_format && !act)
+        return kErrBadArgument; // (the quantised output is the SiLU-mul epilogue's)
+    if (out_format && (n % 512 != 0 || ((uintptr_t)c & 15)))
+        return kErrProblemShape; // the consumer's K = n / 2 must be a whole number of 256-column producer tiles
+    if (a_format && ((uintptr_t)a & 15))
+        return kErrBadArgument;
 
     const int dev = current_device();
     const bool is_auto = is_auto_id(solution_id);
     const int klass = auto_class(solution_id);
     if (klass != kClassExact && b_type != kDataTypeMxFp4e2m1)
         return kErrKernelShape; // the native class exists for MXFP4 weights only (e4m3 group scales are not E8M0 block scales)
+    if (restrict_ && is_auto && klass == kClassExact)
+        return kErrKernelShape; // quantised I/O is the native class's: name it (a sentinel or an explicit native id)
+    if (a_format && klass != kClassExact && (unsigned)klass != a_format)
+        return kErrKernelShape; // activations quantised to one format, kernel class of the other
     const SolutionEntry *entry = nullptr;
     unsigned splitk = 1;
     if (is_auto) {
         // $PETIT_AMD_AUTOTUNE=1: a problem no table knows is tuned once, here, before its first real launch (tune.hip)
         if (klass == kClassExact && !act && autotune_enabled() && tuned_solution(dev, hints->a_type, b_type, m, n, k, kClassExact) == 0)
             autotune_on_first_sight(b_type, c, a, b, scales, global_scale, m, n, k, hints->a_type, stream);
-        const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k, klass);
+        const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k, klass, restrict_);
         entry = ch.entry, splitk = ch.splitk;
         if (!entry)
             return kErrKernelShape;
@@ -514,6 +543,8 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             return kErrKernelShape;
         if (act && (!act_ok(*entry) || splitk != 1))
             return kErrKernelShape; // needs an even number of n-tiles per wave and no cross-workgroup K split
+        if (!entry_allows(*entry, restrict_) || (a_format && (unsigned)entry_class(*entry) != a_format))
+            return kErrKernelShape;
     }
 
     GemmArgs args{};
@@ -521,7 +552,9 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     args.m = m, args.n = n, args.k = k;
     args.bias = epilogue ? epilogue->bias : nullptr;
     args.act = act ? 1u : 0u;
-    uint64_t need = workspace_need(*entry, splitk, m, n, k);
+    args.qa = a_format ? (const void *)a : nullptr, args.qa_format = a_format, args.out_format = out_format;
+    const bool have_qa = a_format != 0;
+    uint64_t need = workspace_need(*entry, splitk, m, n, k, have_qa);
     if (need) {
         void *ws = nullptr;
         if (call_ws) {
@@ -534,11 +567,12 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             if (busy && !is_auto)
                 return kErrBadArgument; // the registered workspace is bound to another stream: pass one per call
         }
-        if (!ws && klass != kClassExact && call_ws && call_ws_bytes >= workspace_need(*entry, 1, m, n, k)) {
-            ws = call_ws, splitk = 1; // native default pick with a K split, scratch covers the activations only: the same kernel unsplit
-            need = workspace_need(*entry, 1, m, n, k);
+        if (!ws && klass != kClassExact && splitk > 1 && (have_qa || (call_ws && call_ws_bytes >= workspace_need(*entry, 1, m, n, k)))) {
+            splitk = 1; // native default pick with a K split, scratch covers the activations only (or they came quantised): the same kernel unsplit
+            need = workspace_need(*entry, 1, m, n, k, have_qa);
+            ws = need ? call_ws : nullptr;
         }
-        if (!ws) {
+        if (!ws && need) {
             if (!is_auto || klass != kClassExact)
                 return kErrKernelShape; // explicit id (or the native class) that needs scratch nobody provided
             // AUTO without scratch: the best kernel that needs none (not the K-split pick minus its split: a tiled kernel
@@ -627,6 +661,63 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
     const SolutionEntry *e = find_explicit(fam, solution_id);
     const unsigned splitk = solution_splitk(solution_id);
     return e && splitk ? workspace_need(*e, splitk, m, n, k) : 0;
+}
+
+static bool native_args_ok(const petit_native_args *na) {
+    return !na || (na->struct_bytes == sizeof(petit_native_args) && na->reserved == 0 &&
+                   (na->a_format == 0 || na->a_format == 8 || na->a_format == 4) && (na->out_format == 0 || na->out_format == 8 || na->out_format == 4));
+}
+
+int petit_gemm_mxfp4_native(void *c, const void *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,
+                            unsigned n, unsigned k, const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
+                            const petit_native_args *native, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!native_args_ok(native))
+        return kErrBadArgument;
+    const NativeIo io{native ? (unsigned)native->a_format : 0u, native ? (unsigned)native->out_format : 0u};
+    if (solution_id == PETIT_SOLUTION_AUTO)
+        return kErrKernelShape; // this entry point is the native class's: name a sentinel or a native kernel id
+    return gemm_impl(kDataTypeMxFp4e2m1, (unsigned *)c, (const unsigned *)a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue,
+                     workspace, workspace_bytes, stream, &io);
+}
+
+uint64_t petit_gemm_native_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id,
+                                           const petit_epilogue *epilogue, const petit_native_args *native) {
+    Family fam;
+    bool ok;
+    const bool act = epilogue_act(epilogue, &ok);
+    if (!ok || !native_args_ok(native) || !hints || hints->c_type != hints->a_type || hints->b_type != kDataTypeMxFp4e2m1 ||
+        !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0 || solution_id == PETIT_SOLUTION_AUTO)
+        return 0;
+    const unsigned a_format = native ? (unsigned)native->a_format : 0u, out_format = native ? (unsigned)native->out_format : 0u;
+    const unsigned restrict_ = (a_format ? kNeedK32 : 0u) | (out_format ? kNeedQuantOut : 0u);
+    const SolutionEntry *e = nullptr;
+    unsigned splitk = 1;
+    if (is_auto_id(solution_id)) {
+        const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, auto_class(solution_id), restrict_);
+        e = ch.entry, splitk = ch.splitk;
+    } else {
+        e = find_explicit(fam, solution_id);
+        splitk = solution_splitk(solution_id);
+    }
+    return e && splitk ? workspace_need(*e, splitk, m, n, k, a_format != 0) : 0;
+}
+
+uint64_t petit_quantized_activation_bytes(unsigned m, unsigned k, int format) {
+    return format == 8 ? native32_ws_bytes<8>(m, k) : format == 4 ? native32_ws_bytes<4>(m, k) : 0;
+}
+
+int petit_quantize_activations(void *qa, const void *a, unsigned m, unsigned k, int a_type, int format, void *stream) {
+    if (m == 0 || k == 0)
+        return kOk;
+    if (!qa || !a || ((uintptr_t)qa & 15) || ((uintptr_t)a & 15))
+        return kErrBadArgument;
+    if (k % 256 != 0)
+        return kErrProblemShape;
+    if (a_type == kDataTypeBf16)
+        return quantize32_bf16(a, qa, m, k, format, (hipStream_t)stream);
+    if (a_type == kDataTypeFp16)
+        return quantize32_f16(a, qa, m, k, format, (hipStream_t)stream);
+    return kErrKernelShape;
 }
 
 uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,

@@ -234,8 +234,8 @@ __device__ __forceinline__ void c_tile_store(const u32x4 *img, void *c, unsigned
 // the GEMM's N, `up` the same columns of the second half; out[j] = silu(y_gate[j]) * y_up[j], y = acc*gs + bias,
 // rounded once.  bias (if any) spans the full N: gate part at n, up part at n + n_half.
 template <class AT>
-__device__ __forceinline__ uint2 finish4_silu_mul(const f32x4 gate, const f32x4 up, const float gs, const void *bias,
-                                                  const unsigned n, const unsigned n_half) {
+__device__ __forceinline__ f32x4 silu_mul4(const f32x4 gate, const f32x4 up, const float gs, const void *bias, const unsigned n,
+                                           const unsigned n_half) {
     float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
         auto load4 = [&](unsigned col, float *b) {
@@ -254,12 +254,18 @@ __device__ __forceinline__ uint2 finish4_silu_mul(const f32x4 gate, const f32x4 
         load4(n, bg);
         load4(n + n_half, bu);
     }
-    float o[4];
+    f32x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float g = __builtin_fmaf(gate[i], gs, bg[i]), u = __builtin_fmaf(up[i], gs, bu[i]);
         o[i] = g / (1.0f + __expf(-g)) * u;
     }
+    return o;
+}
+template <class AT>
+__device__ __forceinline__ uint2 finish4_silu_mul(const f32x4 gate, const f32x4 up, const float gs, const void *bias,
+                                                  const unsigned n, const unsigned n_half) {
+    const f32x4 o = silu_mul4<AT>(gate, up, gs, bias, n, n_half);
     uint2 r;
     r.x = pack2(AT{}, o[0], o[1]);
     r.y = pack2(AT{}, o[2], o[3]);

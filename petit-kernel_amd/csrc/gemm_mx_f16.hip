@@ -5,4 +5,5 @@
 #define PETIT_TU_TABLE solutions_mx_f16
 #define PETIT_TU_SPLIT 1
 #define PETIT_TU_NATIVE_AT Fp16
+#define PETIT_TU_QUANTIZE quantize32_f16
 #include "stream_tu.inc"

@@ -125,6 +125,100 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
     }
 }
 
+// The SiLU-mul epilogue as a PRODUCER of quantised activations (out_format 8 / 4; 128 x 256 workgroup tiles only: NP = 2, four waves).
+// A gated MLP is gate_up -> SiLU-mul -> down; with 16-bit hand-over the native path pays a quantiser launch in front of each GEMM
+// (5-6 us each at M = 512, 15-19 % of `o`).  Here the gate_up kernel writes what `down`'s kernel reads: out[m][j], j < N/2, quantised
+// per 32 columns to MXFP8 / MXFP4 with the quantiser's own rule (E8M0 scale from the block maximum), in the k-tile-major scratch
+// layout described above -- a 256-column workgroup tile produces exactly ONE 128-column k-tile of the consumer for its 128 rows, a
+// contiguous 8 / 16 KiB run plus 512 scale bytes.  The values are quantised from the f32 SiLU-mul result (one rounding, where
+// "round to 16 bit, then quantise" has two).
+//   lane (m, h) of wave wn holds, for each of the wave's two output tiles np, columns {0-3, 8-11} (h = 0) or {4-7, 12-15} (h = 1): a
+//   32-column block is the wave's two tiles of one row, i.e. this lane's 16 values and its partner's (lane ^ 32) 16.  The block
+//   maximum needs one cross-half swap; a second swap (of the packed codes) leaves lane h with ALL 16 columns of tile np = h, so each
+//   lane stores 8 (FP4) / 16 (FP8) contiguous bytes.
+template <class AT, int OUTF, int MB>
+__device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][2], const float gs, const void *bias, unsigned char *out,
+                                                        const unsigned m_total, const unsigned n_half, const unsigned m_first,
+                                                        const unsigned col0, const unsigned kt, const unsigned wn, const unsigned m_l,
+                                                        const unsigned h, unsigned char *lds_scales, const unsigned m0, const unsigned tid) {
+    constexpr unsigned kRowB = 16 * OUTF; // bytes per row and k-tile: 128 (FP8) / 64 (FP4)
+    unsigned char *const qs = out + (size_t)m_total * (n_half / 8 * OUTF);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const unsigned m = m_first + mb * 32;
+        f32x4 v[2][2];
+        float amax = 0.f;
+#pragma unroll
+        for (int np = 0; np < 2; ++np)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x16 &a = acc[mb][np];
+                v[np][u] = silu_mul4<AT>(f32x4{a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]},
+                                         f32x4{a[8 + 4 * u], a[8 + 4 * u + 1], a[8 + 4 * u + 2], a[8 + 4 * u + 3]}, gs, bias,
+                                         col0 + np * 16 + u * 8 + 4 * h, n_half);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    amax = fmaxf(amax, fabsf(v[np][u][i]));
+            }
+        {
+            const unsigned au = __builtin_bit_cast(unsigned, amax);
+            const auto sw = __builtin_amdgcn_permlane32_swap(au, au, false, false);
+            const unsigned s0 = sw[0], s1 = sw[1];
+            amax = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
+        }
+        // the quantiser's rule (quantize_act32_kernel): E8M0 scale 2^(E - emax_elem), E = exponent of the block maximum
+        constexpr unsigned kEmax = OUTF == 8 ? 7u : 2u;
+        const unsigned ebits = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+        unsigned sbyte = amax == 0.f ? 127u : (ebits > kEmax ? ebits - kEmax : 1u);
+        sbyte = sbyte > 254u ? 254u : sbyte;
+        if (h == 0)
+            lds_scales[(mb * 32 + m_l) * 4 + wn] = (unsigned char)sbyte;
+        if constexpr (OUTF == 4) {
+            const float scale = __builtin_bit_cast(float, sbyte << 23);
+            unsigned q[2];
+#pragma unroll
+            for (int np = 0; np < 2; ++np) {
+                unsigned w = 0;
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[np][0][0], v[np][0][1], scale, 0);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[np][0][2], v[np][0][3], scale, 1);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[np][1][0], v[np][1][1], scale, 2);
+                w = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(w, v[np][1][2], v[np][1][3], scale, 3);
+                q[np] = w;
+            }
+            // lane h now gets tile np = h whole: r0 = the {0-3, 8-11} bytes, r1 = the {4-7, 12-15} bytes
+            const auto sw = __builtin_amdgcn_permlane32_swap(q[0], q[1], false, false);
+            const unsigned r0 = sw[0], r1 = sw[1];
+            uint2 o;
+            o.x = __builtin_amdgcn_perm(r1, r0, 0x05040100u); // columns 0-7
+            o.y = __builtin_amdgcn_perm(r1, r0, 0x07060302u); // columns 8-15
+            if (m < m_total)
+                *reinterpret_cast<uint2 *>(out + ((size_t)kt * m_total + m) * kRowB + 16 * wn + 8 * h) = o;
+        } else {
+            const float inv = __builtin_bit_cast(float, (254u - sbyte) << 23); // 2^-(sbyte - 127)
+            unsigned d[2][2];
+#pragma unroll
+            for (int np = 0; np < 2; ++np)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int w = 0;
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[np][u][0] * inv, v[np][u][1] * inv, w, false);
+                    w = __builtin_amdgcn_cvt_pk_fp8_f32(v[np][u][2] * inv, v[np][u][3] * inv, w, true);
+                    d[np][u] = (unsigned)w;
+                }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(d[0][0], d[1][0], false, false); // columns 0-3 | 4-7 of tile np = h
+            const auto s1 = __builtin_amdgcn_permlane32_swap(d[0][1], d[1][1], false, false); // columns 8-11 | 12-15
+            const unsigned a0 = s0[0], a1 = s0[1], b0 = s1[0], b1 = s1[1];
+            // the 16-column unit u16 = 2 wn + h sits at position pos of the tile's 128 bytes (the operand order of the layout note)
+            const unsigned u16 = 2 * wn + h, pos = (u16 & 4u) | ((u16 & 1u) << 1) | ((u16 >> 1) & 1u);
+            if (m < m_total)
+                *reinterpret_cast<u32x4 *>(out + ((size_t)kt * m_total + m) * kRowB + pos * 16) = u32x4{a0, a1, b0, b1};
+        }
+    }
+    __syncthreads();
+    if (tid < (unsigned)(32 * MB) && m0 + tid < m_total)
+        *reinterpret_cast<unsigned *>(qs + ((size_t)kt * m_total + m0 + tid) * 4) = reinterpret_cast<const unsigned *>(lds_scales)[tid];
+}
+
 //   MB, NP, WAVES, D as in WideCfg; ACT = 8 (MXFP8 activations) or 4 (MXFP4 activations).
 //   KT   k-tiles per barrier ("stage"): the quantised activation tile is small (128 / 64 bytes per row and k-tile), and with
 //        zero unpack work a k-tile is only 2*MB*NP MFMAs, so one barrier per tile leaves the wave waiting on it.
@@ -470,6 +564,18 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     const float gs = *p.gs;
     if (p.act) {
         const unsigned n_half = p.n >> 1;
+        if constexpr (NP == 2 && WM == 1 && WAVES == 4) {
+            if (p.out_format) { // (workgroup-uniform) the launcher admits it for full 256-column tiles only: n % 512 == 0
+                __syncthreads(); // the stages are dead: their LDS holds the scale bytes of the tile
+                unsigned char *const lds_sc = reinterpret_cast<unsigned char *>(smem);
+                const unsigned col0 = (nt0 >> 1) * 16;
+                if (p.out_format == 4)
+                    n32_silu_quant_epilogue<AT, 4, MB>(acc, gs, p.bias, (unsigned char *)p.c, p.m, n_half, m_base, col0, bn, wn, m_l, h, lds_sc, m0, tid);
+                else
+                    n32_silu_quant_epilogue<AT, 8, MB>(acc, gs, p.bias, (unsigned char *)p.c, p.m, n_half, m_base, col0, bn, wn, m_l, h, lds_sc, m0, tid);
+                return;
+            }
+        }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll

@@ -43,6 +43,11 @@ struct GemmArgs {
     unsigned m, n, k;
     unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))
     unsigned flags;          // large-M kernels: kFlagPrio | kFlagXcdRaster (launch_flags(), stream_tu.inc)
+    // native-FP4 pipeline (gemm_native32.hpp): activations the CALLER already holds quantised (no quantiser launch), and a
+    // SiLU-mul epilogue that emits the NEXT GEMM's quantised activations instead of a 16-bit matrix
+    const void *qa;          // pre-quantised activations in the k-tile-major scratch layout of format qa_format, or null
+    unsigned qa_format;      // 8 (MXFP8) / 4 (MXFP4) when qa is set
+    unsigned out_format;     // 0: c is a 16-bit matrix; 8 / 4: c receives [m][n/2] activations quantised to MXFP8 / MXFP4 (act = 1 only)
 };
 enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u };
 
@@ -51,9 +56,14 @@ enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u };
 struct petit_solution_hints;
 struct petit_epilogue;
 namespace petit_amd {
+// native pipeline options of a call (petit_gemm_mxfp4_native): a_format 8 / 4 = `a` already holds quantised activations,
+// out_format 8 / 4 = the SiLU-mul epilogue emits quantised activations instead of a 16-bit matrix
+struct NativeIo {
+    unsigned a_format, out_format;
+};
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,
               unsigned n, unsigned k, const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue, void *call_ws,
-              uint64_t call_ws_bytes, void *stream);
+              uint64_t call_ws_bytes, void *stream, const NativeIo *io = nullptr);
 int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, unsigned k, uint64_t max_ws, uint64_t *ids, uint64_t *needs,
                     int cap);
 

@@ -115,5 +115,8 @@ const SolutionEntry *solutions_nv_bf16(int *count);
 const SolutionEntry *solutions_nv_f16(int *count);
 const SolutionEntry *solutions_mx_bf16(int *count);
 const SolutionEntry *solutions_mx_f16(int *count);
+// the activation quantiser of the 32x32x64 native kernels, stand-alone (gemm_mx_{bf16,f16}.hip): format 8 = MXFP8, 4 = MXFP4
+int quantize32_bf16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);
+int quantize32_f16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);
 
 } // namespace petit_amd

@@ -13,6 +13,7 @@ import enum
 import torch
 
 from . import compiled, offline, ops, tuning
+from .ops import QuantizedActivations, mul_mxfp4_native, quantize_activations
 from .tuning import tune, tune_tensors
 from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
 
@@ -80,6 +81,9 @@ __all__ = [
     "PetitSolutionHints",
     "tune",
     "tune_tensors",
+    "quantize_activations",
+    "mul_mxfp4_native",
+    "QuantizedActivations",
     "SOLUTION_AUTO",
     "SOLUTION_AUTO_NATIVE_MXFP8",
     "SOLUTION_AUTO_NATIVE_MXFP4",

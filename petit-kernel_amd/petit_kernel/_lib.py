@@ -40,6 +40,11 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("activation", C.c_int32), ("reserved", C.c_int32)]
 
 
+class NativeArgs(C.Structure):
+    """petit_native_args (include/petit_amd.h)."""
+    _fields_ = [("struct_bytes", C.c_uint32), ("a_format", C.c_int32), ("out_format", C.c_int32), ("reserved", C.c_int32)]
+
+
 class TuneParams(C.Structure):
     """petit_tune_params (include/petit_amd.h)."""
     _fields_ = [("struct_bytes", C.c_uint32), ("klass", C.c_int32), ("n_copies", C.c_uint32), ("launches", C.c_uint32),
@@ -82,6 +87,12 @@ _SIGNATURES = {
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
     "petit_enable_native_fp4": (C.c_int, [C.c_int]),
     "petit_native_workspace_bytes": (C.c_uint64, [C.c_uint, C.c_uint]),
+    "petit_gemm_mxfp4_native": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 + [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue),
+                                          C.POINTER(NativeArgs), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "petit_gemm_native_workspace_bytes": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Epilogue),
+                                                       C.POINTER(NativeArgs)]),
+    "petit_quantized_activation_bytes": (C.c_uint64, [C.c_uint, C.c_uint, C.c_int]),
+    "petit_quantize_activations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
     "petit_gemm_tune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(SolutionHints),
                                   C.POINTER(TuneParams), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
     "petit_tune_insert": (C.c_int, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint64]),

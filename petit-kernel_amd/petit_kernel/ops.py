@@ -342,3 +342,88 @@ def set_workspace(buf) -> None:
     with torch.cuda.device(buf.device):
         _lib.lib.petit_set_workspace(_ptr(buf), C.c_uint64(buf.numel() * buf.element_size()))
         _workspace_keepalive[buf.device.index] = buf
+
+
+# --- the native class as a pipeline (include/petit_amd.h "The native class as a PIPELINE"; no counterpart in the reference) ---
+
+_QFORMATS = {"mxfp8": 8, "mxfp4": 4}
+
+
+class QuantizedActivations:
+    """Activations [m, k] quantised to MXFP8 / MXFP4 in the layout the 32x32x64 native kernels read ("petit-qact/1": opaque
+    bytes, k-tile major).  Produced by quantize_activations() or by mul_mxfp4_a16(..., activation="silu_mul",
+    out_quantized=...); consumed by mul_mxfp4_a16(a=<this>, ...)."""
+
+    def __init__(self, data: torch.Tensor, m: int, k: int, fmt: str, dtype: torch.dtype):
+        self.data, self.m, self.k, self.fmt, self.dtype = data, m, k, fmt, dtype
+
+    def __repr__(self) -> str:
+        return f"QuantizedActivations(m={self.m}, k={self.k}, fmt={self.fmt!r}, dtype={self.dtype}, {self.data.numel()} bytes)"
+
+
+def quantize_activations(A: torch.Tensor, fmt: str = "mxfp4") -> QuantizedActivations:
+    """16-bit activations [m, k] -> QuantizedActivations (one launch; share the result among GEMMs with the same input)."""
+    _check(fmt in _QFORMATS, "fmt must be 'mxfp8' or 'mxfp4'")
+    _check(A.is_cuda and A.is_contiguous() and A.dim() == 2 and A.dtype in (torch.bfloat16, torch.float16),
+           "A must be a contiguous 2-D bfloat16 / float16 GPU tensor")
+    m, k = A.shape
+    nbytes = int(_lib.lib.petit_quantized_activation_bytes(m, k, _QFORMATS[fmt]))
+    qa = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    with torch.cuda.device(A.device):
+        rc = _lib.lib.petit_quantize_activations(_ptr(qa), _ptr(A), m, k, _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16,
+                                                 _QFORMATS[fmt], _stream(A))
+    if rc == _lib.PETIT_ERROR_PROBLEM_SHAPE:
+        raise RuntimeError(f"Incompatible problem shape (m={m}, k={k})")
+    _raise_on(rc, "quantize_activations")
+    return QuantizedActivations(qa, m, k, fmt, A.dtype)
+
+
+def mul_mxfp4_native(A, B, s, global_scale, size_m, size_n, size_k, solution_id=SOLUTION_AUTO_NATIVE_MXFP4, bias=None, activation=None,
+                     out_quantized=None):
+    """The native-FP4 class with its hand-over points (petit_gemm_mxfp4_native).  A: a 16-bit [size_m, size_k] tensor (quantised
+    by the call: two launches) or QuantizedActivations (one launch).  out_quantized 'mxfp8' / 'mxfp4' (with activation='silu_mul'):
+    returns QuantizedActivations [size_m, size_n / 2] for the next GEMM instead of a 16-bit tensor.
+    solution_id: SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4 (-2 / -3) or an explicit native kernel id."""
+    pre = isinstance(A, QuantizedActivations)
+    if pre:
+        _check(A.m == size_m and A.k == size_k, f"quantised activations are [{A.m}, {A.k}], the call says [{size_m}, {size_k}]")
+        a_t, dtype, a_fmt, dev = A.data, A.dtype, _QFORMATS[A.fmt], A.data.device
+    else:
+        _check(A.is_cuda and A.is_contiguous() and A.numel() == size_m * size_k and A.dtype in (torch.bfloat16, torch.float16),
+               "A must be a contiguous [size_m, size_k] bfloat16 / float16 GPU tensor")
+        a_t, dtype, a_fmt, dev = A, A.dtype, 0, A.device
+    _check(B.is_cuda and s.is_cuda and global_scale.is_cuda, "all tensors must be on GPU")
+    _check(B.is_contiguous() and B.numel() * B.element_size() == size_n * size_k // 2, "B does not hold size_n * size_k packed 4-bit weights")
+    _check(s.is_contiguous() and s.numel() * s.element_size() == size_n * size_k // 32, "s does not hold size_n * size_k / 32 scales")
+    _check(activation in _ACTIVATIONS, f"activation must be one of {sorted(k for k in _ACTIVATIONS if k)} or None")
+    _check(out_quantized is None or out_quantized in _QFORMATS, "out_quantized must be None, 'mxfp8' or 'mxfp4'")
+    act = _ACTIVATIONS[activation]
+    out_fmt = _QFORMATS[out_quantized] if out_quantized else 0
+    _check(not out_fmt or act, "out_quantized needs activation='silu_mul'")
+    a_type = _lib.CXX_DTYPE_BF16 if dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
+    hints = _CHints(a_type, _lib.CXX_DTYPE_MXFP4_E2M1, a_type, 0)
+    sid = _c_solution_id(solution_id)
+    epi = None
+    if bias is not None or act:
+        if bias is not None:
+            _check(bias.is_cuda and bias.device == dev and bias.dtype == dtype and bias.is_contiguous() and bias.numel() == size_n,
+                   "bias must be a contiguous [size_n] tensor of the activation dtype on the same device")
+        epi = _lib.Epilogue(bias.data_ptr() if bias is not None else None, act, 0)
+    na = _lib.NativeArgs(C.sizeof(_lib.NativeArgs), a_fmt, out_fmt, 0)
+    epi_p = C.byref(epi) if epi is not None else None
+    if out_fmt:
+        c = torch.empty(int(_lib.lib.petit_quantized_activation_bytes(size_m, size_n // 2, out_fmt)), dtype=torch.uint8, device=dev)
+    else:
+        c = torch.empty((size_m, size_n // 2 if act else size_n), dtype=dtype, device=dev)
+    ws_bytes = int(_lib.lib.petit_gemm_native_workspace_bytes(C.byref(hints), size_m, size_n, size_k, C.c_uint64(sid), epi_p, C.byref(na)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    with torch.cuda.device(dev):
+        err = _lib.lib.petit_gemm_mxfp4_native(_ptr(c), _ptr(a_t), _ptr(B), _ptr(s), _ptr(global_scale), size_m, size_n, size_k, C.byref(hints),
+                                               C.c_uint64(sid), epi_p, C.byref(na), _ptr(ws) if ws is not None else None, C.c_uint64(ws_bytes),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if err == _lib.PETIT_ERROR_PROBLEM_SHAPE:
+        raise RuntimeError(f"Incompatible problem shape (m={size_m}, n={size_n}, k={size_k})")
+    if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
+        raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
+    _raise_on(err, "mul_mxfp4_native")
+    return QuantizedActivations(c, size_m, size_n // 2, out_quantized, dtype) if out_fmt else c

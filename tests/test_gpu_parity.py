@@ -1517,9 +1517,12 @@ ref = a.float() @ dense.t()
 assert torch.allclose(c1.float(), ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item())
 pk.mul_nvfp4_a16(a, b, sp, gs, m, n, k, -1)
 assert _lib.lib.petit_tune_generation() == g0 + 1, 'second call must not tune again'
+a9 = a[:9].contiguous()
+pk.mul_nvfp4_a16(a9, b, sp, gs, 9, n, k, -1)
+assert _lib.lib.petit_tune_generation() == g0 + 1, 'same M bucket: the row serves it'
 gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr):
-    pk.mul_nvfp4_a16(a, b, sp, gs, 9, n, k, -1)      # same M bucket (9..16): served by the row, nothing to tune under capture
+    pk.mul_nvfp4_a16(a9, b, sp, gs, 9, n, k, -1)      # same M bucket (9..16): served by the row, nothing to tune under capture
 gr.replay(); torch.cuda.synchronize()
 print('%%x' %% picked)
 """ % (ROOT / "petit-kernel_amd", ROOT)
@@ -1529,3 +1532,176 @@ print('%%x' %% picked)
     picked = out.stdout.strip().splitlines()[-1]
     rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
     assert ["5", "3", "1536", "3072"] == rows[0][:4] and rows[0][6] == picked
+
+
+# --- the native class as a pipeline: pre-quantised activations in, quantised SiLU-mul out (petit_gemm_mxfp4_native) --------
+
+def decode_qact(raw: np.ndarray, m: int, k: int, fmt: str) -> np.ndarray:
+    """'petit-qact/1' bytes -> the dequantised [m, k] activations (csrc/gemm_native32.hpp, workspace layout note): data
+    [K/128][M][16 ACT bytes] then scales [K/128][M][4] E8M0 bytes; FP4: natural nibble order; FP8: the eight 16-column units of a
+    tile sit at positions (u & 4) | ((u & 1) << 1) | ((u >> 1) & 1)."""
+    act = 8 if fmt == "mxfp8" else 4
+    kt = k // 128
+    data = raw[: m * k // 8 * act].reshape(kt, m, 16 * act)
+    sc = raw[m * k // 8 * act:].reshape(kt, m, 4).astype(np.int32)
+    scale = np.ldexp(1.0, sc - 127)                                      # [kt][m][4 blocks of 32]
+    if act == 4:
+        lo, hi = data & 0xF, data >> 4
+        codes = np.stack([lo, hi], axis=-1).reshape(kt, m, 128)
+        vals = O.FP4_VALUES[codes]
+    else:
+        vals8 = torch.from_numpy(data.copy()).view(torch.float8_e4m3fn).float().numpy().reshape(kt, m, 8, 16)
+        pos = [(u & 4) | ((u & 1) << 1) | ((u >> 1) & 1) for u in range(8)]
+        vals = vals8[:, :, pos, :].reshape(kt, m, 128)
+    out = vals.reshape(kt, m, 4, 32) * scale[..., None]
+    return out.reshape(kt, m, 128).transpose(1, 0, 2).reshape(m, k).astype(np.float32)
+
+
+def _mx_problem_on_device(pk, m, n, k, seed, dtype=torch.bfloat16):
+    a_bits, q, s, gs = random_problem("mx", m, n, k, seed, dtype == torch.bfloat16)
+    a = from_bits(a_bits, dtype).to(DEV)
+    b = pk.repack_mxfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+    sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+    return a_bits, q, s, gs, a, b, sp, torch.tensor([gs], dtype=torch.float32, device=DEV)
+
+
+@pytest.mark.parametrize("fmt,code", [("mxfp8", 2), ("mxfp4", 6)])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512), (1, 128, 768)])
+def test_prequantized_activations_equal_on_the_fly(pk, m, n, k, fmt, code):
+    """quantize_activations() once + the GEMM on the quantised bytes (ONE launch) is bit-identical to the two-launch call on
+    the 16-bit activations, for every 32x32x64 kernel of the format, the class sentinel and a K split; the decoded bytes are
+    exactly the CPU statement of the quantiser; a 16x16x128 kernel (other operand order) and a format mismatch are refused."""
+    a_bits, q, s, gs, a, b, sp, gsd = _mx_problem_on_device(pk, m, n, k, 6100 + m + n + k)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16
+    h.b_type = pk.DataType.mxfloat4_e2m1
+    qa = pk.quantize_activations(a, fmt)
+    want = quantize_act_mxfp8(to_f32(a_bits, True)) if fmt == "mxfp8" else quantize_act_mxfp4(to_f32(a_bits, True))
+    assert np.array_equal(decode_qact(qa.data.cpu().numpy(), m, k, fmt), want)
+    pk.ops.enable_native_fp4(True)
+    try:
+        sols = pk.ops.get_fp4_solutions(h, m, n, k)
+        k32 = [x for x in sols if (x >> 48) & 0xF == 13 and (x >> 32) & 7 == code]
+        assert k32
+        sentinel = pk.SOLUTION_AUTO_NATIVE_MXFP8 if fmt == "mxfp8" else pk.SOLUTION_AUTO_NATIVE_MXFP4
+        for sid in k32 + [(k32[0] & ~(0xF << 60)) | (2 << 60), sentinel]:
+            two = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, sid) if sid != sentinel else None
+            one = pk.mul_mxfp4_native(qa, b, sp, gsd, m, n, k, sid)
+            if two is None:      # the sentinel may resolve to a 16x16x128 kernel for 16-bit input; with quantised input it must be a 32x32x64 one
+                two = pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, k32[0])
+                assert check_gemm(bits(one), to_f32(bits(two), True), True) is None
+            else:
+                assert torch.equal(one.view(torch.int16), two.view(torch.int16)), hex(sid)
+        k16 = [x for x in sols if (x >> 48) & 0xF == 9]
+        if k16 and fmt == "mxfp8":
+            with pytest.raises(RuntimeError):
+                pk.mul_mxfp4_native(qa, b, sp, gsd, m, n, k, k16[0])
+        other = pk.SOLUTION_AUTO_NATIVE_MXFP4 if fmt == "mxfp8" else pk.SOLUTION_AUTO_NATIVE_MXFP8
+        with pytest.raises(RuntimeError):
+            pk.mul_mxfp4_native(qa, b, sp, gsd, m, n, k, other)
+        with pytest.raises(RuntimeError):
+            pk.mul_mxfp4_native(qa, b, sp, gsd, m, n, k, -1)           # plain AUTO never runs the native class
+    finally:
+        pk.ops.enable_native_fp4(False)
+
+
+@pytest.mark.parametrize("fmt", ["mxfp8", "mxfp4"])
+@pytest.mark.parametrize("m,n,k,with_bias", [(64, 512, 1024, False), (130, 1024, 512, True), (512, 1536, 2048, False), (5, 512, 768, False)])
+def test_quantized_silu_mul_output_feeds_the_next_gemm(pk, m, n, k, with_bias, fmt):
+    """gate_up with the quantising SiLU-mul epilogue (out_quantized): the emitted bytes decode to the 16-bit fused result within
+    one quantisation step of their block (scale byte = the quantiser's rule on the block maximum), and `down` run on them equals
+    `down` run on quantize_activations(16-bit result) up to the double rounding the fused form avoids."""
+    a_bits, q, s, gs, a, b, sp, gsd = _mx_problem_on_device(pk, m, n, k, 7300 + m + n + k)
+    bias = (torch.randn(n, device=DEV) * 0.5).bfloat16() if with_bias else None
+    sentinel = pk.SOLUTION_AUTO_NATIVE_MXFP8 if fmt == "mxfp8" else pk.SOLUTION_AUTO_NATIVE_MXFP4
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16
+    h.b_type = pk.DataType.mxfloat4_e2m1
+    c16 = pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, sentinel, bias=bias, activation="silu_mul")
+    qout = pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, sentinel, bias=bias, activation="silu_mul", out_quantized=fmt)
+    assert isinstance(qout, pk.QuantizedActivations) and (qout.m, qout.k, qout.fmt) == (m, n // 2, fmt)
+    ref16 = c16.float().cpu().numpy()
+    deq = decode_qact(qout.data.cpu().numpy(), m, n // 2, fmt)
+    blk = np.abs(ref16).reshape(m, -1, 32).max(axis=2)
+    step = np.repeat(np.ldexp(1.0, np.floor(np.log2(np.maximum(blk, 1e-30)))), 32, axis=1).reshape(m, -1)   # 2^E of the block maximum
+    err = np.abs(deq - ref16)
+    if fmt == "mxfp4":      # e2m1 on [0, 8) 2^(E-2): spacing <= 2^(E-1), saturation of (6, 8) costs up to 2^(E-1) more
+        assert (err <= 0.5 * step + 2.0 ** -7 * np.abs(ref16)).all(), err.max()
+    else:                   # e4m3: 2^-4 relative, block maximum mapped into [128, 256) (never saturates)
+        assert (err <= 2.0 ** -4 * np.abs(ref16) + 2.0 ** -9 * step + 2.0 ** -7 * np.abs(ref16)).all(), err.max()
+    assert np.sqrt(np.mean(err ** 2)) <= (0.15 if fmt == "mxfp4" else 0.03) * np.sqrt(np.mean(ref16 ** 2))
+    # the consumer: down = [n2, n / 2] MXFP4 weights
+    n2 = 256
+    _, q2, s2, gs2 = random_problem("mx", 1, n2, n // 2, 99 + n, True)
+    b2 = pk.repack_mxfp4(torch.from_numpy(q2).to(DEV).view(torch.int32), n2, n // 2)
+    sp2 = pk.process_mxfp4_scales(torch.from_numpy(s2).to(DEV), n2, n // 2)
+    gsd2 = torch.tensor([gs2], dtype=torch.float32, device=DEV)
+    y_fused = pk.mul_mxfp4_native(qout, b2, sp2, gsd2, m, n2, n // 2, sentinel).float()
+    y_two = pk.mul_mxfp4_native(pk.quantize_activations(c16, fmt), b2, sp2, gsd2, m, n2, n // 2, sentinel).float()
+    diff = (y_fused - y_two).pow(2).mean().sqrt().item() / max(y_two.pow(2).mean().sqrt().item(), 1e-9)
+    assert diff <= (0.08 if fmt == "mxfp4" else 0.02), diff
+    # and it really is the dequantised bytes that were multiplied: the oracle on `deq`
+    dq2 = O.dequant_mxfp4(q2, s2)
+    _, want = O.gemm_ref(O.f32_to_bf16_bits(deq), True, dq2, gs2)
+    check_gemm(bits(pk.mul_mxfp4_native(qout, b2, sp2, gsd2, m, n2, n // 2, sentinel)), want, True,
+               (np.abs(deq) @ np.abs(dq2).T) * gs2)
+    # what the entry point refuses
+    pk.ops.enable_native_fp4(True)
+    try:
+        small = next(x for x in pk.ops.get_fp4_solutions(h, m, n, k) if (x >> 48) & 0xF == 13 and (x >> 52) & 0xF == 2)
+        with pytest.raises(RuntimeError):
+            pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, small, activation="silu_mul", out_quantized=fmt)   # 128-column tiles
+    finally:
+        pk.ops.enable_native_fp4(False)
+    with pytest.raises(RuntimeError):
+        pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, sentinel, out_quantized=fmt)                             # no SiLU-mul
+
+
+def test_mlp_block_accuracy_budget(pk):
+    """SURVEY.md section 8 f3 / the reference's model-level claim (README.md:3): an accuracy budget for the native class beyond
+    one GEMM.  A synthetic gated-MLP block x -> gate_up -> SiLU-mul -> down (hidden 2048, intermediate 4096, MXFP4 weights,
+    M = 96 tokens) with OUTLIER CHANNELS in x (six input columns x 60, the shape LLM activations have), three ways:
+      exact  : the default kernels (bf16 activations end to end, fused SiLU-mul),
+      mxfp8  : the native pipeline, activations quantised to MXFP8 at both GEMMs (quantiser + 2 launches),
+      mxfp4  : the same with MXFP4 activations,
+    each against the f64 oracle of the block.  Errors are reported relative to the rms of the block's output and bounded with
+    margin over what MI355X measured."""
+    import json
+    hid, inter, m = 2048, 4096, 96
+    rng = np.random.default_rng(2026)
+    x = rng.standard_normal((m, hid), dtype=np.float32)
+    x[:, rng.choice(hid, 6, replace=False)] *= 60.0
+    x_bits = O.f32_to_bf16_bits(x)
+    _, q1, s1, _ = random_problem("mx", 1, 2 * inter, hid, 11, True, mx_band=(122, 127))
+    _, q2, s2, _ = random_problem("mx", 1, hid, inter, 12, True, mx_band=(122, 127))
+    gs1, gs2 = 0.05, 0.05
+    dq1, dq2 = O.dequant_mxfp4(q1, s1).astype(np.float64), O.dequant_mxfp4(q2, s2).astype(np.float64)
+    xf = to_f32(x_bits, True).astype(np.float64)
+    y1 = xf @ dq1.T * gs1
+    act = y1[:, :inter] / (1.0 + np.exp(-y1[:, :inter])) * y1[:, inter:]
+    ref = act @ dq2.T * gs2
+    rms = np.sqrt(np.mean(ref ** 2))
+    xd = from_bits(x_bits, torch.bfloat16).to(DEV)
+    b1 = pk.repack_mxfp4(torch.from_numpy(q1).to(DEV).view(torch.int32), 2 * inter, hid)
+    sp1 = pk.process_mxfp4_scales(torch.from_numpy(s1).to(DEV), 2 * inter, hid)
+    b2 = pk.repack_mxfp4(torch.from_numpy(q2).to(DEV).view(torch.int32), hid, inter)
+    sp2 = pk.process_mxfp4_scales(torch.from_numpy(s2).to(DEV), hid, inter)
+    g1, g2 = torch.tensor([gs1], device=DEV), torch.tensor([gs2], device=DEV)
+    out = {}
+    h1 = pk.mul_mxfp4_a16(xd, b1, sp1, g1, m, 2 * inter, hid, -1, activation="silu_mul")
+    out["exact"] = pk.mul_mxfp4_a16(h1, b2, sp2, g2, m, hid, inter, -1)
+    for fmt, sid in (("mxfp8", pk.SOLUTION_AUTO_NATIVE_MXFP8), ("mxfp4", pk.SOLUTION_AUTO_NATIVE_MXFP4)):
+        hq = pk.mul_mxfp4_native(pk.quantize_activations(xd, fmt), b1, sp1, g1, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=fmt)
+        out[fmt] = pk.mul_mxfp4_native(hq, b2, sp2, g2, m, hid, inter, sid)
+    report = {}
+    for name, y in out.items():
+        e = y.float().cpu().numpy().astype(np.float64) - ref
+        report[name] = {"rms_err_over_rms": float(np.sqrt(np.mean(e ** 2)) / rms), "max_err_over_rms": float(np.abs(e).max() / rms)}
+    print("mlp block accuracy budget:", json.dumps(report))
+    dump = ROOT / "gpurun_out"
+    if dump.is_dir():
+        (dump / "mlp_accuracy_budget.json").write_text(json.dumps({"hidden": hid, "intermediate": inter, "m": m, "outlier_columns": 6,
+                                                                   "outlier_factor": 60, "errors_relative_to_output_rms": report}, indent=1))
+    assert report["exact"]["rms_err_over_rms"] <= 1e-2
+    assert report["mxfp8"]["rms_err_over_rms"] <= 8e-2
+    assert report["mxfp4"]["rms_err_over_rms"] <= 0.45
