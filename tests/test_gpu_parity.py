@@ -1623,7 +1623,7 @@ def test_quantized_silu_mul_output_feeds_the_next_gemm(pk, m, n, k, with_bias, f
     ref16 = c16.float().cpu().numpy()
     deq = decode_qact(qout.data.cpu().numpy(), m, n // 2, fmt)
     blk = np.abs(ref16).reshape(m, -1, 32).max(axis=2)
-    step = np.repeat(np.ldexp(1.0, np.floor(np.log2(np.maximum(blk, 1e-30)))), 32, axis=1).reshape(m, -1)   # 2^E of the block maximum
+    step = np.repeat(np.exp2(np.floor(np.log2(np.maximum(blk, 1e-30)))), 32, axis=1).reshape(m, -1)   # 2^E of the block maximum
     err = np.abs(deq - ref16)
     if fmt == "mxfp4":      # e2m1 on [0, 8) 2^(E-2): spacing <= 2^(E-1), saturation of (6, 8) costs up to 2^(E-1) more
         assert (err <= 0.5 * step + 2.0 ** -7 * np.abs(ref16)).all(), err.max()
@@ -1644,7 +1644,7 @@ def test_quantized_silu_mul_output_feeds_the_next_gemm(pk, m, n, k, with_bias, f
     dq2 = O.dequant_mxfp4(q2, s2)
     _, want = O.gemm_ref(O.f32_to_bf16_bits(deq), True, dq2, gs2)
     check_gemm(bits(pk.mul_mxfp4_native(qout, b2, sp2, gsd2, m, n2, n // 2, sentinel)), want, True,
-               (np.abs(deq) @ np.abs(dq2).T) * gs2)
+               (np.abs(deq) @ np.abs(dq2).T) * gs2, sum_abs_coef=1e-4)      # (silu(g) * u of e8m0-scaled weights: terms of 1e12 cancelling)
     # what the entry point refuses
     pk.ops.enable_native_fp4(True)
     try:
