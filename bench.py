@@ -127,12 +127,23 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
         if time.time() - t0 > budget_s:
             notes.append(f"time budget reached before {shape} M={m} {a}x{w} {mode}")
             break
-        n, k = BL.LLAMA70B[shape]
         dtype = torch.bfloat16 if a == "bf16" else torch.float16
         hbm = m <= 16
         out = {"shape": shape, "M": m, "dt": f"{a}x{w}" + ("" if mode == "auto" else f" {mode}")}
+        if shape != "mlp":
+            n, k = BL.LLAMA70B[shape]
         try:
-            if mode == "hipblaslt":
+            if shape == "mlp":      # gate_up -> SiLU-mul -> down of Llama-3-70B as one unit (BL.MlpBlock)
+                if "mlp" not in weights:
+                    weights.clear()
+                    torch.cuda.empty_cache()
+                    weights["mlp"] = BL.MlpBlock(m, dev)
+                blk = weights["mlp"]
+                print(f"[bench] cell mlp M={m} {mode}", file=sys.stderr, flush=True)
+                r = blk.time(mode[4:], stream)
+                pk_peak = BL.BF16_PEAK_TFLOPS if mode == "mlp_exact" else BL.FP8_PEAK_TFLOPS if "mxfp8" in mode else BL.FP4_PEAK_TFLOPS
+                out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "TF": round(r["tflops"], 1), "frac": round(r["tflops"] / pk_peak, 4)})
+            elif mode == "hipblaslt":
                 weights.clear()
                 torch.cuda.empty_cache()
                 hb = BL.HipblasLtGemm(m, n, k, dtype, dev)

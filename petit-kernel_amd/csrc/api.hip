@@ -340,14 +340,14 @@ const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, 
     for (int i = 0; i < fam.count; ++i) {
         const SolutionEntry &e = fam.entries[i];
         const StreamShape &s = e.shape;
-        if (entry_class(e) != klass || !entry_fits(e, m, k) || s.wm != 1 || (need_pairs && !act_ok(e)) || !entry_allows(e, restrict_))
-            continue;
+        if (entry_class(e) != klass || !entry_fits(e, m, k) || s.wm == 2 || (need_pairs && !act_ok(e)) || !entry_allows(e, restrict_))
+            continue; // (wm = 2: two waves along M, a measured loser kept as a tested instance; wm = 3: two K groups)
         const bool k32 = s.am == kNative32Am;
         const unsigned bm = (k32 ? 32u : 16u) * s.mt, bn = 16u * s.wn * s.nt;
         const bool two = k32 && klass == kClassNativeFp4 && s.mt * s.nt == 16 && s.d == 2; // Native32Cfg::kMinWavesPerSimd
         double tflops; // sustained by this tile shape when the chip is full
         if (k32 && klass == kClassNativeFp4)
-            tflops = two ? 3300.0 : (s.mt * s.nt == 16 ? 2300.0 : 2500.0) + 50.0 * ((s.wk / 4 == 2) + (s.wk % 4 == 2));
+            tflops = two ? 3300.0 : (s.mt * s.nt == 16 ? 2300.0 : 2500.0) + 50.0 * ((s.wk / 4 == 2) + (s.wk % 4 == 2)) + (s.wm == 3 ? 300.0 : 0.0);
         else if (k32)
             tflops = 2000.0;
         else
@@ -899,9 +899,10 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kOk;
     }
     if (s.am == kNative32Am) {
-        snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt / s.wm, s.nt / 2, s.wm, s.wn, s.d,
-                 s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * s.wm);
+        const int wm = s.wm == 2 ? 2 : 1, kgrp = s.wm == 3 ? 2 : 1;
+        snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, s.d,
+                 s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * wm * kgrp);
         return kOk;
     }
     if (s.am == kWideAm) {

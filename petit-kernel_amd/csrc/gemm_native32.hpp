@@ -231,21 +231,27 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
 //        of a column stream the SAME weight tiles (the second request hits the CU's L1).  WM = 2 puts two waves on every
 //        SIMD for the same 128 x 128 workgroup tile: with one wave per SIMD the stage's DMA / LDS reads / W refills and its
 //        MFMAs were issued by the same in-order instruction stream and did not overlap (0.25 MFMA utilisation measured).
-template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1> struct Native32Cfg {
+//   KG   wave GROUPS along K inside the workgroup (1 or 2).  KG = 2: the workgroup is two complete copies of the KG = 1 wave set,
+//        each with its own LDS stages and weight ring, walking one half of the workgroup's K range; their accumulators are summed
+//        through LDS before the epilogue.  Two waves per SIMD that share NOTHING (WM = 2 shares the weight tiles and lost): what a
+//        second workgroup on the CU gives the 128 x 256 kernel, for shapes whose grid is only one 128 x 128 tile per CU (N <= 10240
+//        at M = 512: `o`, qkv).
+template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1, int KG_ = 1> struct Native32Cfg {
     using AT = AT_;
     static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, PF = PF_, NBUF = PF_ + 1;
-    static constexpr int WM = WM_, kWaves = WAVES * WM;
-    static constexpr int kThreads = 64 * kWaves;
+    static constexpr int WM = WM_, kWaves = WAVES * WM, KG = KG_;
+    static constexpr int kThreads = 64 * kWaves * KG;
+    static_assert(KG == 1 || (KG == 2 && WM == 1), "two K groups only with one wave along M");
     static constexpr int BM = 32 * MB * WM;
     static constexpr int kRowU4 = ACT;                        // 16-byte units per LDS row: 128 B (FP8) / 64 B (FP4)
     static constexpr int kDataU4 = BM * kRowU4;               // one tile image
-    static constexpr int kScaleU4 = (BM + 3) / 4 < kThreads / 4 ? kThreads / 4 : (BM + 3) / 4; // one dword per row (wave-loads of 64)
+    static constexpr int kScaleU4 = (BM + 3) / 4 < kWaves * 16 ? kWaves * 16 : (BM + 3) / 4; // one dword per row (wave-loads of 64)
     static constexpr int kRowsPerLoad = 64 / kRowU4;          // rows one 1 KiB wave-load covers: 8 / 16
     static constexpr int kDataLoads = BM / kRowsPerLoad / kWaves;
     static_assert(ACT == 8 || ACT == 4, "activations are quantised to MXFP8 or MXFP4");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(WM == 1 || WM == 2, "one or two waves along M");
-    static_assert(BM % (kRowsPerLoad * kWaves) == 0 && BM <= kThreads, "A tile must split evenly over the waves");
+    static_assert(BM % (kRowsPerLoad * kWaves) == 0 && BM <= 64 * kWaves, "A tile must split evenly over the waves");
     static_assert((kRowsPerLoad * kWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
     static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4);   // one stage: KT tile images, then their KT scale arrays
     static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
@@ -254,9 +260,11 @@ template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, in
     static constexpr int BN = 32 * NP * WAVES;
     // 128 x 256 / 256 x 128 with a two-tile ring: asked to fit two workgroups per CU (256 registers, 128 of them accumulators):
     // 3/4 of the operand bytes per flop of 128 x 128 AND a second workgroup to overlap with (gate_up M = 512: 158 -> 144 us)
-    static constexpr int kMinWavesPerSimd = (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2) ? 2 : 1; // (MXFP8 fragments are twice the size: spills)
+    static constexpr int kMinWavesPerSimd = (KG == 2 || (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2)) ? 2 : 1; // (MXFP8 fragments are twice the size: spills)
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
-    static constexpr int kSmemU4 = NBUF * kStageU4 > kCTileU4 ? NBUF * kStageU4 : kCTileU4;
+    static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;       // KG = 2: the second group's accumulators, f32
+    static constexpr int kSmemU4a = KG * NBUF * kStageU4 > kCTileU4 ? KG * NBUF * kStageU4 : kCTileU4;
+    static constexpr int kSmemU4 = kSmemU4a > kRedU4 ? kSmemU4a : kRedU4;
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
 };
 
@@ -284,11 +292,15 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     // NBUF stages of [KT tile images][KT scale arrays]
     __shared__ u32x4 smem[Cfg::kSmemU4];
 
+    constexpr int KG = Cfg::KG;
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned kg = KG == 1 ? 0u : wave_all / kWaves;          // K group of this wave
+    const unsigned wave = KG == 1 ? wave_all : wave_all % kWaves;  // index inside the group
     const unsigned wn = WM == 1 ? wave : wave % WAVES, wm = WM == 1 ? 0u : wave / WAVES; // (the WM waves of a column: wave, wave + WAVES)
     const unsigned m_l = lane & 31u, h = lane >> 5;
+    u32x4 *const smem_g = smem + kg * (NBUF * Cfg::kStageU4);      // this group's LDS stages
 
     const unsigned ktiles = p.k / kTileK;
     const unsigned nspans = ktiles / KS;
@@ -297,7 +309,12 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     tile_of_block(p.flags, bn, bm);
     const unsigned nt0 = (bn * WAVES + wn) * (2 * NP);
     const unsigned m0 = bm * Cfg::BM;
-    const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
+    // K slice of this wave group: part blockIdx.z * KG + kg of spans_per_wave spans each.  A part past the end (possible for the
+    // LAST group of a KG = 2 workgroup only) walks the last span with every weight row masked off (valid_nt = 0: zeros in, zeros
+    // accumulated) instead of branching around the MFMA stream, and then keeps the barrier count of its partner.
+    const unsigned part_begin = (blockIdx.z * KG + kg) * p.spans_per_wave;
+    const bool empty_part = KG == 2 && part_begin >= nspans;
+    const unsigned sp_begin = min(part_begin, nspans - 1);
     const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
     const unsigned kt_begin = sp_begin * KS;
 
@@ -310,7 +327,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             for (int v = 0; v < 16; ++v)
                 acc[mb][np][v] = 0.f;
 
-    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)(2 * NP), ntiles - nt0) : 0u;
+    const unsigned valid_nt = (nt0 < ntiles && !empty_part) ? min((unsigned)(2 * NP), ntiles - nt0) : 0u;
     const unsigned w_row_bytes = ktiles * kTileBytes;
     const unsigned s_row_bytes = p.k / 2;
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
@@ -345,12 +362,12 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 #if defined(__HIP_DEVICE_COMPILE__) && !(PETIT_ABLATE_N32 & 1)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
-            u32x4 *const data = smem + buf * Cfg::kStageU4 + t * Cfg::kDataU4;
+            u32x4 *const data = smem_g + buf * Cfg::kStageU4 + t * Cfg::kDataU4;
 #pragma unroll
             for (int i = 0; i < Cfg::kDataLoads; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * kWaves + wave) * 64), 16,
                                                          dma_voff, i * (RPL * kWaves) * kRowB + (kt + t) * qa_tile, 0, 0);
-            u32x4 *const sc = smem + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
+            u32x4 *const sc = smem_g + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, (kt + t) * qs_tile, 0, 0);
         }
 #else
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             constexpr int S = decltype(s_c)::value, T0 = S * KT; // stage S of the span: k-tiles T0 .. T0 + KT - 1
             constexpr bool kNextStage = !kLast || (T0 + KT < KS);
             const unsigned kt = kt0 + T0;
-            const u32x4 *const stage = smem + cur_buf * Cfg::kStageU4;
+            const u32x4 *const stage = smem_g + cur_buf * Cfg::kStageU4;
             const unsigned char *const stage_sc = reinterpret_cast<const unsigned char *>(stage + KT * Cfg::kDataU4);
             // request the stage PF ahead: everybody left that LDS stage at the barrier that ended the previous stage
             if constexpr (PF == 1) {
@@ -541,11 +558,43 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 #endif
         }
 
+    if constexpr (KG == 2) {
+        // a group with fewer spans than its partner (the last part of an odd split) keeps the partner's barrier count: a span is
+        // KS / KT barriers (the prologue's stands in for the one the last stage does not execute)
+        for (unsigned i = sp_end - sp_begin; i < p.spans_per_wave; ++i)
+            for (int b = 0; b < KS / KT; ++b)
+                __builtin_amdgcn_s_barrier();
+        // sum the two groups: group 1 parks its accumulators in LDS (one f32 per lane and register: conflict-free), group 0 adds
+        __syncthreads(); // every stage is dead
+        float *const red = reinterpret_cast<float *>(smem);
+        if (kg == 1) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        red[(((wn * MB + mb) * NP + np) * 16 + v) * 64 + lane] = acc[mb][np][v];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        acc[mb][np][v] += red[(((wn * MB + mb) * NP + np) * 16 + v) * 64 + lane];
+        }
+    }
+
     if constexpr (PETIT_ABLATE_N32 & 16)
         return;
     // --- epilogue: the 32x32 accumulator layout of gemm_wide.hpp
     const unsigned m_base = m0 + wm * (32 * MB) + m_l;
     if (gridDim.z > 1) {
+        if (KG == 2 && kg != 0)
+            return;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -564,7 +613,9 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     const float gs = *p.gs;
     if (p.act) {
         const unsigned n_half = p.n >> 1;
-        if constexpr (NP == 2 && WM == 1 && WAVES == 4) {
+        if (KG == 2 && kg != 0)
+            return;
+        if constexpr (NP == 2 && WM == 1 && WAVES == 4 && KG == 1) {
             if (p.out_format) { // (workgroup-uniform) the launcher admits it for full 256-column tiles only: n % 512 == 0
                 __syncthreads(); // the stages are dead: their LDS holds the scale bytes of the tile
                 unsigned char *const lds_sc = reinterpret_cast<unsigned char *>(smem);
@@ -604,7 +655,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 const unsigned nt = 2 * np + (u >> 1);
                 const unsigned n = (nt0 + nt) * 16 + (u & 1) * 8 + 4 * h;
                 const f32x4 v = f32x4{acc[mb][np][4 * u], acc[mb][np][4 * u + 1], acc[mb][np][4 * u + 2], acc[mb][np][4 * u + 3]};
-                if (nt < valid_nt) // (bias is read at n: only for columns that exist)
+                if (nt < valid_nt && (KG == 1 || kg == 0)) // (bias is read at n: only for columns that exist)
                     c_tile_put<Cfg::BN>(smem, (wm * MB + mb) * 32 + m_l, (wn * 2 * NP + nt) * 16 + (u & 1) * 8 + 4 * h,
                                         finish4<AT>(v, gs, p.bias, n));
             }

@@ -1098,7 +1098,9 @@ def test_bench_cells_parity(pk):
     import sys
     sys.path.insert(0, str(ROOT / "tools"))
     import benchlib as BL
-    plan = [c for c in BL.bench_cell_plan() if c["mode"] != "hipblaslt"]
+    full_plan = BL.bench_cell_plan()
+    assert [c["mode"] for c in full_plan if c["shape"] == "mlp"] == ["mlp_" + m_ for m_ in BL.MlpBlock.MODES]   # -> test_bench_mlp_block_cells
+    plan = [c for c in full_plan if c["mode"] != "hipblaslt" and c["shape"] != "mlp"]
     assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx")}
     assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512}          # configs[1..2] + M = 512
     ran = 0
@@ -1128,6 +1130,45 @@ def test_bench_cells_parity(pk):
             del P
             torch.cuda.empty_cache()
     assert ran == len(plan)
+
+
+def test_bench_mlp_block_cells(pk):
+    """The gated-MLP cells of bench.py (tools/benchlib.py MlpBlock: Llama-3-70B gate_up -> SiLU-mul -> down at M = 512, MXFP4
+    weights) at full size, through the same calls: the exact path against the oracle (sampled columns of h, then `down` on the
+    GPU's own h), the native pipelines against the exact result at the class tolerance and against each other."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import benchlib as BL
+    m, hid, inter = 512, 8192, 28672
+    P1 = FullSizeProblem(pk, "mx", 2 * inter, hid, 4001)
+    P2 = FullSizeProblem(pk, "mx", hid, inter, 4002)
+    x_bits = P1.activations(m, True, 4003)
+    x = from_bits(x_bits, torch.bfloat16).to(DEV)
+    gs = P1.gsd
+    h = pk.mul_mxfp4_a16(x, P1.b, P1.sp, gs, m, 2 * inter, hid, -1, activation="silu_mul")
+    cols = np.unique(np.random.default_rng(5).integers(0, inter, 48))
+    dq = O.dequant_mxfp4(np.concatenate([P1.q[cols], P1.q[cols + inter]]), np.concatenate([P1.s[cols], P1.s[cols + inter]])).astype(np.float64)
+    y1 = to_f32(x_bits, True).astype(np.float64) @ dq.T * P1.gs
+    g, u = y1[:, : len(cols)], y1[:, len(cols):]
+    want = g / (1.0 + np.exp(-g)) * u
+    got = h[:, torch.from_numpy(cols).to(DEV)].float().cpu().numpy().astype(np.float64)
+    assert (np.abs(got - want) <= 2e-2 * np.abs(want) + 2e-2 * np.sqrt(np.mean(want ** 2))).all()
+    y_exact = pk.mul_mxfp4_a16(h, P2.b, P2.sp, P2.gsd, m, hid, inter, -1)
+    P2.check_sampled(y_exact, bits(h), True, "down on the GPU's h")
+    ye = y_exact.float()
+    rms = ye.pow(2).mean().sqrt().item()
+    outs = {}
+    for fmt, sid in (("mxfp4", pk.SOLUTION_AUTO_NATIVE_MXFP4), ("mxfp8", pk.SOLUTION_AUTO_NATIVE_MXFP8)):
+        h4 = pk.mul_mxfp4_native(x, P1.b, P1.sp, gs, m, 2 * inter, hid, sid, activation="silu_mul")
+        outs[fmt + "_4launch"] = pk.mul_mxfp4_native(h4, P2.b, P2.sp, P2.gsd, m, hid, inter, sid).float()
+        hq = pk.mul_mxfp4_native(pk.quantize_activations(x, fmt), P1.b, P1.sp, gs, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=fmt)
+        outs[fmt + "_pipeline"] = pk.mul_mxfp4_native(hq, P2.b, P2.sp, P2.gsd, m, hid, inter, sid).float()
+    for name, y in outs.items():
+        rel = (y - ye).pow(2).mean().sqrt().item() / rms
+        assert rel <= (0.45 if "mxfp4" in name else 0.08), (name, rel)
+    for fmt, tol in (("mxfp4", 0.12), ("mxfp8", 0.03)):
+        rel = (outs[fmt + "_pipeline"] - outs[fmt + "_4launch"]).pow(2).mean().sqrt().item() / rms
+        assert rel <= tol, (fmt, rel)
 
 
 # the kernels whose step-ending wait is a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (a wrong count is a timing-dependent

@@ -53,6 +53,8 @@ def bench_cell_plan() -> list:
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
                  dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt")]
+    # the gated-MLP block (gate_up -> SiLU-mul -> down) as a unit: what the quantising epilogue buys the native class
+    plan += [dict(shape="mlp", M=512, a="bf16", w="mx", mode="mlp_" + mode) for mode in MlpBlock.MODES]
     return plan
 
 
@@ -175,6 +177,45 @@ class Gemm:
         med = median(us)
         return {"us": med, "us_min": min(us), "us_max": max(us), "launches": launches, "reps": reps,
                 "gbs": nbytes / med / 1e3, "tflops": 2.0 * self.m * self.w.n * self.w.k / med / 1e6, "bytes": nbytes}
+
+
+class MlpBlock:
+    """One gated-MLP block of Llama-3-70B at M tokens, MXFP4 weights: h = silu_mul(x . Wgu^T), y = h . Wd^T, three ways:
+      exact                     default kernels (bf16 activations), fused SiLU-mul: 2 launches
+      native_mxfp4_4launch      the native class call by call: quantiser + GEMM, twice: 4 launches
+      native_mxfp4_pipeline     quantise x once, gate_up emits the quantised h (out_quantized), down reads it: 3 launches
+    (petit_kernel.mul_mxfp4_native; weights of both GEMMs rotate over copies so that nothing is served by the Infinity Cache)."""
+
+    MODES = ("exact", "native_mxfp4_4launch", "native_mxfp4_pipeline", "native_mxfp8_pipeline")
+
+    def __init__(self, m: int, dev, hidden: int = 8192, inter: int = 28672, rotate_mb: int = 1280):
+        self.m, self.hidden, self.inter = m, hidden, inter
+        self.w1 = Weights("mx", 2 * inter, hidden, rotate_mb // 2, dev, seed=11)
+        self.w2 = Weights("mx", hidden, inter, rotate_mb // 2, dev, seed=12)
+        gen = torch.Generator(device=dev).manual_seed(3)
+        self.x = torch.randn((m, hidden), generator=gen, device=dev, dtype=torch.float32).bfloat16()
+        self.gs = torch.tensor([0.02], dtype=torch.float32, device=dev)
+        self.flops = 2.0 * m * hidden * (2 * inter) + 2.0 * m * inter * hidden
+
+    def run(self, mode: str, i: int = 0):
+        import petit_kernel as pk
+        (b1, s1), (b2, s2) = self.w1[i], self.w2[i]
+        m, hid, inter, gs = self.m, self.hidden, self.inter, self.gs
+        if mode == "exact":
+            h = pk.mul_mxfp4_a16(self.x, b1, s1, gs, m, 2 * inter, hid, -1, activation="silu_mul")
+            return pk.mul_mxfp4_a16(h, b2, s2, gs, m, hid, inter, -1)
+        fmt = "mxfp8" if "mxfp8" in mode else "mxfp4"
+        sid = pk.SOLUTION_AUTO_NATIVE_MXFP8 if fmt == "mxfp8" else pk.SOLUTION_AUTO_NATIVE_MXFP4
+        if mode.endswith("4launch"):
+            h = pk.mul_mxfp4_native(self.x, b1, s1, gs, m, 2 * inter, hid, sid, activation="silu_mul")
+            return pk.mul_mxfp4_native(h, b2, s2, gs, m, hid, inter, sid)
+        hq = pk.mul_mxfp4_native(pk.quantize_activations(self.x, fmt), b1, s1, gs, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=fmt)
+        return pk.mul_mxfp4_native(hq, b2, s2, gs, m, hid, inter, sid)
+
+    def time(self, mode: str, stream, reps: int = 5, launches: int = 8) -> dict:
+        us = time_graph(lambda i: self.run(mode, i), launches, reps, stream)
+        med = median(us)
+        return {"us": med, "us_min": min(us), "tflops": self.flops / med / 1e6, "launches": launches, "reps": reps}
 
 
 # --- the dense 16-bit GEMM comparator: hipBLASLt, explicitly (tools/comparators/hipblaslt_gemm.cc) ---------------------
