@@ -130,10 +130,19 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
         dtype = torch.bfloat16 if a == "bf16" else torch.float16
         hbm = m <= 16
         out = {"shape": shape, "M": m, "dt": f"{a}x{w}" + ("" if mode == "auto" else f" {mode}")}
-        if shape != "mlp":
+        if shape in BL.LLAMA70B:
             n, k = BL.LLAMA70B[shape]
         try:
-            if shape == "mlp":      # gate_up -> SiLU-mul -> down of Llama-3-70B as one unit (BL.MlpBlock)
+            if shape == "tp8_qkv_3x1280":   # three TP-8 q / k / v shards sharing the activation row(s): three launches vs one grouped launch
+                key = ("grp", m)
+                if key not in weights:
+                    weights.clear()
+                    torch.cuda.empty_cache()
+                    weights[key] = BL.GroupedGemm(w, 3, 1280, 8192, m, dtype, dev)
+                print(f"[bench] cell {shape} M={m} {mode}", file=sys.stderr, flush=True)
+                r = weights[key].time(mode, stream)
+                out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "GBs": round(r["gbs"]), "frac": round(r["gbs"] / BL.HBM_PEAK_GBS, 4)})
+            elif shape == "mlp":      # gate_up -> SiLU-mul -> down of Llama-3-70B as one unit (BL.MlpBlock)
                 if "mlp" not in weights:
                     weights.clear()
                     torch.cuda.empty_cache()

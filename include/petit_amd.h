@@ -317,6 +317,29 @@ uint64_t petit_quantized_activation_bytes(unsigned m, unsigned k, int format);
 int petit_quantize_activations(void *qa, const void *a, unsigned m, unsigned k, int a_type, int format, void *stream);
 
 /*
+ * Grouped launch (no counterpart in the reference): up to PETIT_GROUP_MAX weight matrices that share the activation rows --
+ * q / k / v (or their tensor-parallel shards) kept as separate tensors, gate and up, the experts a token routes to -- in ONE
+ * kernel launch: c_i[m][n_i] = a[m][k] . dequant(b_i)[n_i][k]^T * (*global_scale_i) (+ bias_i).  At decode batch sizes a
+ * TP-8 shard's GEMM takes 3-4 us of which ~1.6 us is the dependent-dispatch gap between launches on MI355X; a group pays it
+ * once.  Same numerics, bit for bit, as count separate calls with the same kernel id.
+ *   m <= 16 (larger m is not launch-bound: PETIT_ERROR_KERNEL_SHAPE, call per member); every n_i % 16 == 0, k % 256 == 0;
+ *   hints->b_type selects NVFP4 or MXFP4 for ALL members; solution_id PETIT_SOLUTION_AUTO (picked for the concatenated
+ *   problem) or the id of a decode / staged streaming kernel; no scratch, no SiLU-mul.
+ */
+#define PETIT_GROUP_MAX 8
+typedef struct petit_group_member {
+    void *c;                   /* [m][n] output, hints->c_type */
+    const void *b;             /* packed weights of this member */
+    const void *scales;        /* packed scales */
+    const float *global_scale; /* device pointer */
+    const void *bias;          /* [n] or NULL */
+    uint32_t n;
+    uint32_t reserved;         /* 0 */
+} petit_group_member;
+int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned count, const unsigned *a, unsigned m, unsigned k,
+                                const petit_solution_hints *hints, uint64_t solution_id, void *stream);
+
+/*
  * Tune-and-persist (replaces the reference's `bench_matmul -algo tune`, tools/benchmarks/matmul/main.cc:269-325, which
  * enumerates and times every solution on the user's device but leaves the winning id for the user to carry around).
  *

@@ -172,7 +172,7 @@ double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k,
 // *splitk_out (when given): the heuristic may answer with a K split across workgroups for the tiled kernels (needs scratch:
 // callers without any pass nullptr and get the best kernel that needs none).
 const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsigned k, bool need_pairs = false,
-                               unsigned *splitk_out = nullptr) {
+                               unsigned *splitk_out = nullptr, bool need_grouped = false) {
     if (splitk_out)
         *splitk_out = 1;
     // Rules distilled from the MI355X sweeps (profiles/):
@@ -185,6 +185,8 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     const ArchInfo &arch = arch_info(current_device());
     const unsigned ntiles = n / kTileN;
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    if (m > 16 && need_grouped)
+        return nullptr; // (grouped launches exist for the decode regime)
     if (m > 16) {
         const SolutionEntry *best = nullptr;
         double best_us = 1e30;
@@ -223,7 +225,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         if (best)
             return best;
     }
-    if (m > 8 && ntiles >= 12u * arch.num_cus) {
+    if (m > 8 && ntiles >= 12u * arch.num_cus && !need_grouped) {
         // very wide N (gate_up): the 16 x 256 tiled shape shares one activation tile among 256 columns; the streaming
         // kernel would pull the activations through L2 once per 32-64 columns (measured 52.9 vs 57.0 us at M = 16)
         for (int i = 0; i < fam.count; ++i) {
@@ -241,7 +243,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     double best_score = -1e30;
     for (int i = 0; i < fam.count; ++i) {
         const SolutionEntry &e = fam.entries[i];
-        if (!entry_fits(e, m, k) || (need_pairs && !act_ok(e)))
+        if (!entry_fits(e, m, k) || (need_pairs && !act_ok(e)) || (need_grouped && !e.launch_grouped))
             continue;
         const StreamShape &s = e.shape;
         if (s.mt != want_mt || s.am == kTiledAm || is_native_am(s.am) || s.am == kWideAm || s.wm != 1)
@@ -270,7 +272,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     }
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
-            if (entry_fits(fam.entries[i], m, k) && fam.entries[i].shape.am != kTiledAm &&
+            if (entry_fits(fam.entries[i], m, k) && (!need_grouped || fam.entries[i].launch_grouped) && fam.entries[i].shape.am != kTiledAm &&
                 !is_native_am(fam.entries[i].shape.am) && fam.entries[i].shape.am != kWideAm && (!need_pairs || act_ok(fam.entries[i])) &&
                 (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
@@ -700,6 +702,48 @@ uint64_t petit_gemm_native_workspace_bytes(const petit_solution_hints *hints, un
         splitk = solution_splitk(solution_id);
     }
     return e && splitk ? workspace_need(*e, splitk, m, n, k, a_format != 0) : 0;
+}
+
+int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned count, const unsigned *a, unsigned m, unsigned k,
+                                const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
+    if (count == 0 || m == 0 || k == 0)
+        return kOk;
+    if (!members || !a || !hints || count > (unsigned)kMaxGroup)
+        return kErrBadArgument;
+    if (hints->c_type != hints->a_type)
+        return kErrKernelShape;
+    Family fam;
+    if (!family_for(hints->a_type, hints->b_type, &fam))
+        return kErrKernelShape;
+    GroupTable g{};
+    g.count = count;
+    uint64_t n_total = 0;
+    for (unsigned i = 0; i < count; ++i) {
+        const petit_group_member &mb = members[i];
+        if (!mb.c || !mb.b || !mb.scales || !mb.global_scale || mb.reserved != 0)
+            return kErrBadArgument;
+        if (mb.n == 0 || !shape_ok(mb.n, k))
+            return kErrProblemShape;
+        g.n[i] = mb.n, g.w[i] = mb.b, g.s[i] = mb.scales, g.c[i] = mb.c, g.gs[i] = mb.global_scale, g.bias[i] = mb.bias;
+        n_total += mb.n;
+    }
+    if ((uint64_t)k * 16 * 4 * 2 >= (1ull << 31) || n_total >= (1ull << 31))
+        return kErrProblemShape;
+    if (m > 16)
+        return kErrKernelShape; // grouped launches serve the decode regime (launch-gap-bound shapes); larger M: call per member
+    const SolutionEntry *entry = nullptr;
+    if (solution_id == PETIT_SOLUTION_AUTO) {
+        // the pick for the CONCATENATED problem (the whole grid is what fills the chip), among the kernels that have a grouped form
+        const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, false, m, (unsigned)n_total, k);
+        entry = ch.entry && ch.entry->launch_grouped && ch.splitk == 1 ? ch.entry : heuristic(fam, m, (unsigned)n_total, k, false, nullptr, true);
+    } else {
+        entry = find_explicit(fam, solution_id);
+        if (entry && (!entry_fits(*entry, m, k) || solution_splitk(solution_id) != 1))
+            return kErrProblemShape;
+    }
+    if (!entry || !entry->launch_grouped)
+        return kErrKernelShape;
+    return entry->launch_grouped(g, a, m, k, (hipStream_t)stream);
 }
 
 uint64_t petit_quantized_activation_bytes(unsigned m, unsigned k, int format) {

@@ -92,11 +92,11 @@ __device__ __forceinline__ float sum_rows(float v) {
     return __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1);
 }
 
+// (block_x: the workgroup's index along N -- blockIdx.x for a plain launch, the index inside its member for a grouped one)
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads, Cfg::kWavesPerSimd) void gemm_decode_kernel(const void *arg_w, const void *arg_s, const void *arg_a,
-                                                                    unsigned arg_k, unsigned arg_n, unsigned arg_m,
-                                                                    unsigned arg_spw, unsigned arg_act, void *arg_c,
-                                                                    const float *arg_gs, const void *arg_bias) {
+__device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *arg_s, const void *arg_a, unsigned arg_k, unsigned arg_n,
+                                                 unsigned arg_m, unsigned arg_spw, unsigned arg_act, void *arg_c, const float *arg_gs,
+                                                 const void *arg_bias, const unsigned block_x) {
     using AT = typename Cfg::AT;
     using Frag = typename AT::frag;
     constexpr int KS = Cfg::KS, NT = Cfg::NT, WK = Cfg::WK, D = Cfg::D, R = Cfg::R, TG = Cfg::TG;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kWavesPerSimd) void gemm_decode
     const unsigned ktiles = arg_k / kTileK;
     const unsigned nspans = ktiles / KS;
     const unsigned ntiles = arg_n / kTileN;
-    const unsigned nt0 = blockIdx.x * NT;
+    const unsigned nt0 = block_x * NT;
     const unsigned sp_begin = min(wk * arg_spw, nspans);
     const unsigned sp_end = min(sp_begin + arg_spw, nspans);
 
@@ -354,6 +354,27 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kWavesPerSimd) void gemm_decode
             }
         }
     }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kWavesPerSimd) void gemm_decode_kernel(const void *arg_w, const void *arg_s, const void *arg_a,
+                                                                    unsigned arg_k, unsigned arg_n, unsigned arg_m,
+                                                                    unsigned arg_spw, unsigned arg_act, void *arg_c,
+                                                                    const float *arg_gs, const void *arg_bias) {
+    gemm_decode_body<Cfg>(arg_w, arg_s, arg_a, arg_k, arg_n, arg_m, arg_spw, arg_act, arg_c, arg_gs, arg_bias, blockIdx.x);
+}
+
+// Several weight matrices that share the activation rows (q / k / v shards, gate and up kept apart, the experts of a token) in ONE
+// launch: the grid is the concatenation of the members' grids, a workgroup finds its member by a scalar search over <= 8 prefix
+// sums.  The dependent-dispatch gap (~1.6 us on MI355X, a quarter to a half of a TP-8 shard's whole GEMM) is paid once per group.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads, Cfg::kWavesPerSimd) void gemm_decode_grouped_kernel(const GroupTable g, const void *arg_a, unsigned arg_k,
+                                                                            unsigned arg_m, unsigned arg_spw) {
+    unsigned idx = 0, base = 0;
+    for (unsigned i = 0; i + 1 < g.count; ++i)
+        if (blockIdx.x >= g.wg_end[i])
+            idx = i + 1, base = g.wg_end[i];
+    gemm_decode_body<Cfg>(g.w[idx], g.s[idx], arg_a, arg_k, g.n[idx], arg_m, arg_spw, 0u, g.c[idx], g.gs[idx], g.bias[idx], blockIdx.x - base);
 }
 
 } // namespace petit_amd

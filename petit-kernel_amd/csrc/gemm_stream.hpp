@@ -81,12 +81,11 @@ struct StreamCfg {
 // command processor hands the leading ones to every wave in SGPRs at launch, so a wave computes its first W / scale / A
 // addresses without waiting for the s_load round trip of the kernarg segment -- the decode kernel is all prologue
 // (every wave issues its whole share of loads at once), and that round trip sits in front of all of them.
+// (block_x: the workgroup's index along N -- blockIdx.x for a plain launch, the index inside its member for a grouped one)
 template <class Cfg>
-__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *arg_w, const void *arg_s, const void *arg_a,
-                                                                    unsigned arg_k, unsigned arg_n, unsigned arg_m,
-                                                                    unsigned arg_spw, unsigned arg_act, void *arg_c,
-                                                                    const float *arg_gs, const void *arg_bias,
-                                                                    float *arg_workspace) {
+__device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *arg_s, const void *arg_a, unsigned arg_k, unsigned arg_n,
+                                                 unsigned arg_m, unsigned arg_spw, unsigned arg_act, void *arg_c, const float *arg_gs,
+                                                 const void *arg_bias, float *arg_workspace, const unsigned block_x) {
     GemmArgs p;
     p.c = arg_c, p.a = arg_a, p.w = arg_w, p.s = arg_s, p.gs = arg_gs, p.bias = arg_bias, p.act = arg_act;
     p.workspace = arg_workspace, p.m = arg_m, p.n = arg_n, p.k = arg_k, p.spans_per_wave = arg_spw, p.flags = 0;
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
     const unsigned ktiles = p.k / kTileK;
     const unsigned nspans = ktiles / KS;
     const unsigned ntiles = p.n / kTileN;
-    const unsigned nt0 = (blockIdx.x * WN + wn) * NT;
+    const unsigned nt0 = (block_x * WN + wn) * NT;
     const unsigned m0 = blockIdx.y * (16 * MT);
 
     // K range of this wave: contiguous spans.  gridDim.z splits K across
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
             make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
         const char *a_base = (const char *)p.a + (size_t)m0 * p.k * 2;
         if constexpr (ABL & 32) // tools/ablate: every workgroup reads its own copy of A (is the shared A a hot spot in L2?)
-            a_base += (size_t)(blockIdx.x & 63u) * p.m * p.k * 2;
+            a_base += (size_t)(block_x & 63u) * p.m * p.k * 2;
         const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_base, rows * p.k * 2);
 
         // Everything that decides validity lives in the VGPR offset (bounds
@@ -521,7 +520,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
     // one 8-byte store (or the fp32 slab of this K part when gridDim.z > 1)
     auto emit = [&](f32x4 v, unsigned iwn, unsigned imt, unsigned inn, unsigned il) {
         const unsigned m = m0 + imt * 16 + (il & 15u);
-        const unsigned ntile = (blockIdx.x * WN + iwn) * NT + inn;
+        const unsigned ntile = (block_x * WN + iwn) * NT + inn;
         const unsigned n = ntile * 16 + (il >> 4) * 4;
         if (m >= p.m || ntile >= ntiles)
             return;
@@ -536,7 +535,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
     // an even NT, an even N/16 and gridDim.z == 1)
     auto emit_pair = [&](f32x4 gate, f32x4 up, unsigned iwn, unsigned imt, unsigned inn, unsigned il) {
         const unsigned m = m0 + imt * 16 + (il & 15u);
-        const unsigned ntile = (blockIdx.x * WN + iwn) * NT + inn;
+        const unsigned ntile = (block_x * WN + iwn) * NT + inn;
         if (m >= p.m || ntile >= ntiles)
             return;
         const unsigned n_half = p.n >> 1;
@@ -608,10 +607,32 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
         ts[3] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(p.workspace) +
-                                      ((size_t)blockIdx.x * (WN * WK) + wave) * 4;
+                                      ((size_t)block_x * (WN * WK) + wave) * 4;
             dst[0] = ts[0], dst[1] = ts[1], dst[2] = ts[2], dst[3] = ts[3];
         }
     }
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *arg_w, const void *arg_s, const void *arg_a,
+                                                                    unsigned arg_k, unsigned arg_n, unsigned arg_m,
+                                                                    unsigned arg_spw, unsigned arg_act, void *arg_c,
+                                                                    const float *arg_gs, const void *arg_bias,
+                                                                    float *arg_workspace) {
+    gemm_stream_body<Cfg>(arg_w, arg_s, arg_a, arg_k, arg_n, arg_m, arg_spw, arg_act, arg_c, arg_gs, arg_bias, arg_workspace, blockIdx.x);
+}
+
+// Grouped form (see gemm_decode_grouped_kernel in gemm_decode.hpp): the members' grids concatenated along x; one m-block, no K
+// split across workgroups (grid y = z = 1).
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_grouped_kernel(const GroupTable g, const void *arg_a, unsigned arg_k, unsigned arg_m,
+                                                                            unsigned arg_spw) {
+    unsigned idx = 0, base = 0;
+    for (unsigned i = 0; i + 1 < g.count; ++i)
+        if (blockIdx.x >= g.wg_end[i])
+            idx = i + 1, base = g.wg_end[i];
+    gemm_stream_body<Cfg>(g.w[idx], g.s[idx], arg_a, arg_k, g.n[idx], arg_m, arg_spw, 0u, g.c[idx], g.gs[idx], g.bias[idx], nullptr,
+                          blockIdx.x - base);
 }
 
 // Second pass of the cross-workgroup split-K: sum the fp32 slabs in a fixed

@@ -51,6 +51,20 @@ struct GemmArgs {
 };
 enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u };
 
+// A group of GEMMs that share the activation rows, for the grouped kernels (petit_gemm_fp4_fp16_grouped): passed by value as a
+// kernel argument; wg_end[i] = workgroups of members 0..i (prefix sums along grid x).
+constexpr int kMaxGroup = 8;
+struct GroupTable {
+    unsigned count;
+    unsigned wg_end[kMaxGroup];
+    unsigned n[kMaxGroup];
+    const void *w[kMaxGroup];
+    const void *s[kMaxGroup];
+    void *c[kMaxGroup];
+    const float *gs[kMaxGroup];
+    const void *bias[kMaxGroup];
+};
+
 // api.hip: the dispatcher behind every GEMM entry point (solution_id: explicit id or one of the AUTO sentinels)
 } // namespace petit_amd
 struct petit_solution_hints;

@@ -102,12 +102,15 @@ constexpr unsigned solution_splitk(uint64_t id) { return (unsigned)(id >> 60) & 
 constexpr uint64_t solution_without_splitk(uint64_t id) { return (id & ~((uint64_t)0xf << 60)) | ((uint64_t)1 << 60); }
 
 using LaunchFn = int (*)(const GemmArgs &, unsigned splitk, hipStream_t);
+// several GEMMs sharing the activation rows in one launch (GroupTable, petit_internal.h): the launcher fills wg_end
+using LaunchGroupedFn = int (*)(GroupTable, const void *a, unsigned m, unsigned k, hipStream_t);
 
 struct SolutionEntry {
     StreamShape shape;
     int a_type; // kDataTypeBf16 / kDataTypeFp16
     int fmt;    // kFmtNv / kFmtMx (gemm_stream.hpp)
     LaunchFn launch;
+    LaunchGroupedFn launch_grouped = nullptr; // the decode and the staged streaming kernels have one (M <= 16)
 };
 
 // one table per (activation type, weight format) translation unit

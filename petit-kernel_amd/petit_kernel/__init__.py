@@ -13,7 +13,7 @@ import enum
 import torch
 
 from . import compiled, offline, ops, tuning
-from .ops import QuantizedActivations, mul_mxfp4_native, quantize_activations
+from .ops import QuantizedActivations, mul_fp4_a16_grouped, mul_mxfp4_native, quantize_activations
 from .tuning import tune, tune_tensors
 from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
 
@@ -82,6 +82,7 @@ __all__ = [
     "tune",
     "tune_tensors",
     "quantize_activations",
+    "mul_fp4_a16_grouped",
     "mul_mxfp4_native",
     "QuantizedActivations",
     "SOLUTION_AUTO",

@@ -40,6 +40,12 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("activation", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GroupMember(C.Structure):
+    """petit_group_member (include/petit_amd.h)."""
+    _fields_ = [("c", C.c_void_p), ("b", C.c_void_p), ("scales", C.c_void_p), ("global_scale", C.c_void_p), ("bias", C.c_void_p),
+                ("n", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class NativeArgs(C.Structure):
     """petit_native_args (include/petit_amd.h)."""
     _fields_ = [("struct_bytes", C.c_uint32), ("a_format", C.c_int32), ("out_format", C.c_int32), ("reserved", C.c_int32)]
@@ -87,6 +93,8 @@ _SIGNATURES = {
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
     "petit_enable_native_fp4": (C.c_int, [C.c_int]),
     "petit_native_workspace_bytes": (C.c_uint64, [C.c_uint, C.c_uint]),
+    "petit_gemm_fp4_fp16_grouped": (C.c_int, [C.POINTER(GroupMember), C.c_uint, C.c_void_p, C.c_uint, C.c_uint, C.POINTER(SolutionHints), C.c_uint64,
+                                              C.c_void_p]),
     "petit_gemm_mxfp4_native": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 + [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue),
                                           C.POINTER(NativeArgs), C.c_void_p, C.c_uint64, C.c_void_p]),
     "petit_gemm_native_workspace_bytes": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Epilogue),

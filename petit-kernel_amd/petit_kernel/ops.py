@@ -427,3 +427,41 @@ def mul_mxfp4_native(A, B, s, global_scale, size_m, size_n, size_k, solution_id=
         raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
     _raise_on(err, "mul_mxfp4_native")
     return QuantizedActivations(c, size_m, size_n // 2, out_quantized, dtype) if out_fmt else c
+
+
+# --- grouped launch (include/petit_amd.h "Grouped launch"; no counterpart in the reference) ---------------------------------
+
+def mul_fp4_a16_grouped(kind: str, A: torch.Tensor, members, size_m: int, size_k: int, solution_id: int = -1) -> list:
+    """Up to 8 GEMMs that share the activations A [size_m, size_k] in ONE launch (size_m <= 16): `members` is a list of
+    (B, s, global_scale, size_n) or (B, s, global_scale, size_n, bias) with tensors from repack_* / process_*_scales of `kind`
+    ('nvfp4' / 'mxfp4').  Returns the list of outputs [size_m, size_n_i]; bit-identical to separate calls with the same kernel."""
+    _check(kind in ("nvfp4", "mxfp4"), "kind must be 'nvfp4' or 'mxfp4'")
+    _check(A.dtype in (torch.bfloat16, torch.float16), "A must be bfloat16 or float16.")
+    _check(A.is_cuda and A.is_contiguous() and A.numel() == size_m * size_k, "A must be a contiguous [size_m, size_k] tensor")
+    _check(1 <= len(members) <= 8, "a group holds 1 to 8 members")
+    group = 16 if kind == "nvfp4" else 32
+    arr = (_lib.GroupMember * len(members))()
+    outs = []
+    for i, mem in enumerate(members):
+        B, s, gs, n = mem[:4]
+        bias = mem[4] if len(mem) > 4 else None
+        _check(B.is_cuda and s.is_cuda and gs.is_cuda and B.device == A.device, "all tensors must be on A's GPU")
+        _check(B.is_contiguous() and B.numel() * B.element_size() == n * size_k // 2, "B does not hold size_n * size_k packed 4-bit weights")
+        _check(s.is_contiguous() and s.numel() * s.element_size() == n * size_k // group, f"s does not hold size_n * size_k / {group} scales")
+        _check(gs.dtype == torch.float32 and gs.numel() >= 1, "global_scale must be float32")
+        if bias is not None:
+            _check(bias.is_cuda and bias.dtype == A.dtype and bias.is_contiguous() and bias.numel() == n, "bias must be a contiguous [size_n] tensor of A's dtype")
+        c = torch.empty((size_m, n), dtype=A.dtype, device=A.device)
+        outs.append(c)
+        arr[i] = _lib.GroupMember(c.data_ptr(), B.data_ptr(), s.data_ptr(), gs.data_ptr(), bias.data_ptr() if bias is not None else None, n, 0)
+    a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
+    hints = _CHints(a_type, _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1, a_type, 0)
+    with torch.cuda.device(A.device):
+        err = _lib.lib.petit_gemm_fp4_fp16_grouped(arr, len(members), _ptr(A), size_m, size_k, C.byref(hints), C.c_uint64(_c_solution_id(solution_id)),
+                                                   _stream(A))
+    if err == _lib.PETIT_ERROR_PROBLEM_SHAPE:
+        raise RuntimeError(f"Incompatible problem shape (m={size_m}, k={size_k}, n={[mem[3] for mem in members]})")
+    if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
+        raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
+    _raise_on(err, "mul_fp4_a16_grouped")
+    return outs

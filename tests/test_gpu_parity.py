@@ -1100,7 +1100,8 @@ def test_bench_cells_parity(pk):
     import benchlib as BL
     full_plan = BL.bench_cell_plan()
     assert [c["mode"] for c in full_plan if c["shape"] == "mlp"] == ["mlp_" + m_ for m_ in BL.MlpBlock.MODES]   # -> test_bench_mlp_block_cells
-    plan = [c for c in full_plan if c["mode"] != "hipblaslt" and c["shape"] != "mlp"]
+    assert {c["mode"] for c in full_plan if c["shape"].startswith("tp8")} == {"separate", "grouped"}            # -> test_grouped_launch
+    plan = [c for c in full_plan if c["mode"] != "hipblaslt" and c["shape"] in BL.LLAMA70B]
     assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx")}
     assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512}          # configs[1..2] + M = 512
     ran = 0
@@ -1746,3 +1747,56 @@ def test_mlp_block_accuracy_budget(pk):
     assert report["exact"]["rms_err_over_rms"] <= 1e-2
     assert report["mxfp8"]["rms_err_over_rms"] <= 8e-2
     assert report["mxfp4"]["rms_err_over_rms"] <= 0.45
+
+
+# --- grouped launch: several weight matrices sharing the activation rows in one launch (petit_gemm_fp4_fp16_grouped) ---------
+
+@pytest.mark.parametrize("m", [1, 3, 8, 16])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
+def test_grouped_launch(pk, kind, is_bf16, m):
+    """Members of different N (ragged n-tile counts, one with a bias) against the oracle through solution_id = -1, and, for EVERY
+    kernel that has a grouped form, bit-identical to separate calls with the same id; what the entry point refuses.  Includes the
+    bench cell's shape (three 1280 x 8192 shards, tools/benchlib.py GroupedGemm)."""
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    name = "nvfp4" if kind == "nv" else "mxfp4"
+    for k, ns in ((2048, [256, 96 if kind == "nv" else 64, 1056]), (8192, [1280, 1280, 1280])):
+        a_bits = random_problem(kind, m, 32, k, 900 + m, is_bf16)[0]
+        a = from_bits(a_bits, dtype).to(DEV)
+        members, refs = [], []
+        for i, n in enumerate(ns):
+            _, q, s, gs = random_problem(kind, 1, n, k, 910 + 7 * i + n, is_bf16)
+            b = pk.repack_nvfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+            sp = (pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k) if kind == "nv"
+                  else pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k))
+            gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+            bias = (torch.randn(n, device=DEV) * 0.5).to(dtype) if i == 1 else None
+            members.append((b, sp, gsd, n) + ((bias,) if bias is not None else ()))
+            ref = oracle_ref(kind, a_bits, is_bf16, q, s, gs)
+            if bias is not None:
+                ref = ref + bias.float().cpu().numpy()[None, :]
+            refs.append((ref, oracle_sum_abs(kind, a_bits, is_bf16, q, s, gs)))
+        outs = pk.mul_fp4_a16_grouped(name, a, members, m, k, -1)
+        for c, (ref, sum_abs) in zip(outs, refs):
+            check_gemm(bits(c), ref, is_bf16, sum_abs)
+        if k != 2048:
+            continue
+        h = pk.PetitSolutionHints()
+        h.a_type = h.c_type = dtype
+        h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+        mul = pk.mul_nvfp4_a16 if kind == "nv" else pk.mul_mxfp4_a16
+        grouped_ids = 0
+        for sid in pk.ops.get_fp4_solutions(h, m, ns[0], k):
+            try:
+                outs = pk.mul_fp4_a16_grouped(name, a, members, m, k, sid)
+            except RuntimeError:
+                continue            # a kernel kind without a grouped form
+            grouped_ids += 1
+            for c, mem in zip(outs, members):
+                sep = mul(a, mem[0], mem[1], mem[2], m, mem[3], k, sid, bias=mem[4] if len(mem) > 4 else None)
+                assert torch.equal(c.view(torch.int16), sep.view(torch.int16)), hex(sid)
+        assert grouped_ids >= 3
+    with pytest.raises(RuntimeError):
+        pk.mul_fp4_a16_grouped(name, a, members * 3, m, k, -1)                      # 9 members
+    big = torch.zeros((17, k), dtype=dtype, device=DEV)
+    with pytest.raises(RuntimeError):
+        pk.mul_fp4_a16_grouped(name, big, members, 17, k, -1)                       # not the decode regime

@@ -53,6 +53,8 @@ def bench_cell_plan() -> list:
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
                  dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt")]
+    # launch-gap-bound shapes: the q / k / v shards of a TP-8 deployment (1280 x 8192 each) as three launches and as one grouped launch
+    plan += [dict(shape="tp8_qkv_3x1280", M=m, a="bf16", w="nv", mode=mode) for m in (1, 16) for mode in ("separate", "grouped")]
     # the gated-MLP block (gate_up -> SiLU-mul -> down) as a unit: what the quantising epilogue buys the native class
     plan += [dict(shape="mlp", M=512, a="bf16", w="mx", mode="mlp_" + mode) for mode in MlpBlock.MODES]
     return plan
@@ -177,6 +179,41 @@ class Gemm:
         med = median(us)
         return {"us": med, "us_min": min(us), "us_max": max(us), "launches": launches, "reps": reps,
                 "gbs": nbytes / med / 1e3, "tflops": 2.0 * self.m * self.w.n * self.w.k / med / 1e6, "bytes": nbytes}
+
+
+class GroupedGemm:
+    """`count` weight matrices [n, k] sharing one activation block, as `count` launches (solution_id -1 each) or ONE grouped launch
+    (petit_gemm_fp4_fp16_grouped); every launch of the timed graph reads different weight copies."""
+
+    def __init__(self, fmt: str, count: int, n: int, k: int, m: int, dtype, dev, rotate_mb: int = 1280):
+        self.count, self.n, self.k, self.m, self.dev = count, n, k, m, dev
+        self.w = Weights(fmt, n, k, rotate_mb, dev, max_copies=192)
+        self.g = Gemm(self.w, m, dtype, dev)
+        self.cs = [torch.empty((m, n), dtype=dtype, device=dev) for _ in range(count)]
+        self.bytes = count * (n * k // 2 + n * k // self.w.group + 2 * m * n) + 2 * m * k
+
+    def launch(self, mode: str, i: int):
+        g, stream = self.g, C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if mode == "separate":
+            for j in range(self.count):
+                b, sp = self.w[i * self.count + j]
+                rc = g.fn(C.c_void_p(self.cs[j].data_ptr()), C.c_void_p(g.a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(sp.data_ptr()),
+                          C.c_void_p(g.gs.data_ptr()), self.m, self.n, self.k, C.byref(g.hints), C.c_uint64(_lib.PETIT_SOLUTION_AUTO), None, None,
+                          C.c_uint64(0), stream)
+                assert rc == 0, rc
+        else:
+            arr = (_lib.GroupMember * self.count)()
+            for j in range(self.count):
+                b, sp = self.w[i * self.count + j]
+                arr[j] = _lib.GroupMember(self.cs[j].data_ptr(), b.data_ptr(), sp.data_ptr(), g.gs.data_ptr(), None, self.n, 0)
+            rc = _lib.lib.petit_gemm_fp4_fp16_grouped(arr, self.count, C.c_void_p(g.a.data_ptr()), self.m, self.k, C.byref(g.hints),
+                                                      C.c_uint64(_lib.PETIT_SOLUTION_AUTO), stream)
+            assert rc == 0, rc
+
+    def time(self, mode: str, stream, reps: int = 7, launches: int = 100) -> dict:
+        us = time_graph(lambda i: self.launch(mode, i), launches, reps, stream)
+        med = median(us)
+        return {"us": med, "us_min": min(us), "gbs": self.bytes / med / 1e3}
 
 
 class MlpBlock:
