@@ -18,6 +18,12 @@
 //   R = 1 (M = 1):  a D tile spans two k-tiles (8 MFMAs);  rho = 4g' + 2t + h  <->  tile 2G + t, group 2g' + h
 //   R = 2 (M <= 2): one k-tile (4 MFMAs);                  rho = 4g' + 2m + h  <->  row m,       group 2g' + h
 //   R = 4 (M <= 4): half a k-tile (MFMAs j = 2h, 2h + 1);  rho = 4g' + m       <->  row m,       group 2g' + h
+//   R = 8 (M <= 8): 16 D rows hold 8 activation rows x TWO lane groups only, so a k-tile takes two masked passes ("sets"):
+//                   pass s covers the weights' lane groups g = 2s, 2s + 1;  rho = 8c + m  <->  row m, lane group g = 2s + c,
+//                   group 2g + h.  8 MFMAs per k-tile instead of 4 (the matrix pipe is > 80 % idle at this M), 4 VALU per weight
+//                   word instead of 12.  The accumulator lane (g', n) then needs the scales of lane group 2s + (g' >> 1), not its
+//                   own: the span's scale record is permuted once per span with two lane swaps per dword ([G0 G0 G1 G1] for s = 0,
+//                   [G2 G2 G3 G3] for s = 1).  Pays for bf16 only (the fp16 unpack is 8 VALU per word: neutral).
 //
 // (MFMA j of a tile covers the k-set {128 kt + 32 g + 8 j + i}: lane group g sees group 2g + (j >> 1) of the tile.)
 // The masked activation operand costs no VALU: the wave stages its span of A in a private LDS slice (as the streaming
@@ -58,9 +64,10 @@ template <class AT_, int KS_, int NT_, int WK_, int D_, int R_> struct DecodeCfg
     // resident waves per SIMD the register allocation must allow: four for one n-tile per wave (two 512-thread or four
     // 256-thread workgroups per CU), three otherwise
     static constexpr int kLdsWaves = ((160 * 1024) / (kSmemU4 * 16)) * WK / 4; // what the LDS footprint allows
-    static constexpr int kRegWaves = (NT == 1 && (R == 1 || (R == 2 && D < 8))) ? 4 : 3;
+    static constexpr int kRegWaves = R == 8 ? (NT <= 2 ? 2 : 1) : (NT == 1 && (R == 1 || (R == 2 && D < 8))) ? 4 : 3;
     static constexpr int kWavesPerSimd = kLdsWaves < 1 ? 1 : (kLdsWaves < kRegWaves ? kLdsWaves : kRegWaves);
-    static_assert(R == 1 || R == 2 || R == 4, "rows: 1, 2 or 4");
+    static constexpr int kSets = R == 8 ? 2 : 1;          // masked passes per k-tile
+    static_assert(R == 1 || R == 2 || R == 4 || R == 8, "rows: 1, 2, 4 or 8");
     static_assert(KS % D == 0 && KS % TG == 0, "ring depth must divide the span");
     static_assert(!AT::kSplit && !AT::kBfp, "plain bf16 / fp16 activations");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
@@ -205,28 +212,51 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
         // Fragment pointers: lane (g, rho = r) of the activation operand reads data for the MFMAs whose D row it owns
         // and the zero row for all others.  kBases distinct (tile parity, j >> 1) classes; everything else about a
         // read (k-tile, j & 1) is an immediate offset from the class pointer.
-        constexpr int kBases = 4 / R;
+        constexpr int kBases = R == 8 ? 2 : 4 / R;
         const bool mine = (r >> 2) == g;
         const unsigned key = (R == 1) ? (r & 3u) : (R == 2) ? (r & 1u) : 0u;
-        const unsigned row = (R == 1) ? 0u : (R == 2) ? ((r >> 1) & 1u) : (r & 3u);
+        const unsigned row = (R == 1) ? 0u : (R == 2) ? ((r >> 1) & 1u) : (R == 4) ? (r & 3u) : (r & 7u);
         const u32x4 *fbase[kBases];
 #pragma unroll
-        for (int c = 0; c < kBases; ++c)
-            fbase[c] = a_lds + (int)(((mine && key == (unsigned)c) ? row : (unsigned)R) * Cfg::kARowU4 + g * 4);
+        for (int c = 0; c < kBases; ++c) {
+            // R = 8: base c = pass (set) c; this lane's operand is live in the pass that covers its lane group, for the class its D row names
+            const bool live = R == 8 ? ((g >> 1) == (unsigned)c && (g & 1u) == (r >> 3)) : (mine && key == (unsigned)c);
+            fbase[c] = a_lds + (int)((live ? row : (unsigned)R) * Cfg::kARowU4 + g * 4);
+        }
 
         write_a_stage();
-        Frag afrag[4], anext[4];
-        auto read_frags = [&](Frag(&dst)[4], auto t_c) { // k-tile T of the span now in LDS
+        constexpr int kSets = Cfg::kSets, kFr = 4 * kSets;
+        Frag afrag[kFr], anext[kFr];
+        auto read_frags = [&](Frag(&dst)[kFr], auto t_c) { // k-tile T of the span now in LDS
             constexpr int T = decltype(t_c)::value;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = (R == 1) ? 2 * (T % 2) + (j >> 1) : (R == 2) ? (j >> 1) : 0;
-                dst[j] = __builtin_bit_cast(Frag, fbase[c][T * 16 + j]);
-            }
+            for (int st = 0; st < kSets; ++st)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (R == 8) ? st : (R == 1) ? 2 * (T % 2) + (j >> 1) : (R == 2) ? (j >> 1) : 0;
+                    dst[4 * st + j] = __builtin_bit_cast(Frag, fbase[c][T * 16 + j]);
+                }
         };
         read_frags(afrag, std::integral_constant<int, 0>{});
 
         f32x4 dacc[NT]; // the open D tile (R = 1: lives across the two k-tiles of a pair)
+        // R = 8: the span's scale records as the two passes need them (lane group g' reads the record of lane group 2 s + (g' >> 1))
+        [[maybe_unused]] ScaleRec<kFmtNv, KS> srec8[NT][2];
+        auto permute_recs = [&]() {
+            if constexpr (R == 8) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int d = 0; d < ScaleRec<kFmtNv, KS>::kDwords; ++d) {
+                        const unsigned x = srec[nt].d[d];
+                        const auto a16 = __builtin_amdgcn_permlane16_swap(x, x, false, false); // [G0 G0 G2 G2], [G1 G1 G3 G3]
+                        const unsigned a0 = a16[0], a1 = a16[1];
+                        const auto a32 = __builtin_amdgcn_permlane32_swap(a0, a1, false, false); // [G0 G0 G1 G1], [G2 G2 G3 G3]
+                        srec8[nt][0].d[d] = a32[0], srec8[nt][1].d[d] = a32[1];
+                    }
+            }
+        };
+        permute_recs();
         auto span_body = [&](const unsigned sp, auto last_c) {
             constexpr bool kLast = decltype(last_c)::value;
             const unsigned kt0 = sp * KS;
@@ -247,7 +277,23 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if constexpr (R == 4) {
+                    if constexpr (R == 8) {
+                        // two passes per k-tile, each as the R = 4 form: D tiles (h = 0, 1) of MFMAs (0, 1) and (2, 3)
+                        Frag wv[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            wv[j] = unpack_unscaled(AT{}, wring[SLOT][nt][j]);
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) {
+                            const f32x2 sv = __builtin_amdgcn_cvt_pk_f32_fp8((int)srec8[nt][st].d[T / 2], (T & 1) != 0);
+                            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                            d0 = mfma16(afrag[4 * st + 0], wv[0], d0);
+                            d1 = mfma16(afrag[4 * st + 2], wv[2], d1);
+                            d0 = mfma16(afrag[4 * st + 1], wv[1], d0);
+                            d1 = mfma16(afrag[4 * st + 3], wv[3], d1);
+                            total[nt] += d0 * sv[0] + d1 * sv[1];
+                        }
+                    } else if constexpr (R == 4) {
                         // two D tiles per k-tile: MFMAs 0, 1 see group 2g, MFMAs 2, 3 group 2g + 1
                         const f32x2 sv = __builtin_amdgcn_cvt_pk_f32_fp8((int)srec[nt].d[T / 2], (T & 1) != 0);
                         f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -283,7 +329,7 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
                 }
                 if constexpr (kNextInSpan) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < kFr; ++j)
                         afrag[j] = anext[j];
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -295,6 +341,7 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     srec[nt] = srec_next[nt];
+                permute_recs();
             }
         };
         for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
@@ -306,6 +353,21 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
     float *const red = reinterpret_cast<float *>(smem + WK * Cfg::kALdsU4);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+        if constexpr (R == 8) {
+            // D row rho = 8c + m: accumulator lane (g', n) register i holds row m = 4 (g' & 1) + i; the two classes c = g' >> 1 are
+            // partial sums of the same output: add lanes l and l ^ 32, then lane rows 0 and 1 park rows 0-3 and 4-7
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = total[nt][i];
+                const unsigned u = __builtin_bit_cast(unsigned, v);
+                const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                const unsigned s0 = sw[0], s1 = sw[1];
+                const float sum = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
+                if (g < 2u)
+                    red[((wk * NT + nt) * R + 4 * g + i) * 16 + r] = sum;
+            }
+            continue;
+        }
         float y[R];
         if constexpr (R == 1)
             y[0] = (total[nt][0] + total[nt][1]) + (total[nt][2] + total[nt][3]);
