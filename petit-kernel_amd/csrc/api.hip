@@ -256,7 +256,9 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
         // far better than fragment loads straight from L2 (5120 x 13824, KS = 4, M = 8: 20.6 us direct against ~13 staged)
         score -= am_rows(s.am) == want_am ? 0.0 : (am_rows(s.am) >= (int)m ? 1.0 : 4.0);
         score += 0.5 * (s.am >= kBfpAm); // bf16 x NVFP4, M <= 4: the fp16 pipeline unpacks cheaper
-        score += 0.5 * (s.am >= kDecodeAm); // NVFP4, M <= 4: scale applied after the MFMA, cheaper still (gemm_decode.hpp)
+        // NVFP4, M <= 4: scale applied after the MFMA, cheaper still (gemm_decode.hpp); its 8-row form pays for bf16 only
+        score += 0.5 * (s.am >= kDecodeAm && (am_rows(s.am) <= 4 || e.a_type == kDataTypeBf16));
+        score -= 2.0 * (s.am >= kDecodeAm && am_rows(s.am) == 8 && e.a_type != kDataTypeBf16);
         score -= 1.0 * (s.nt != want_nt);
         // wave count: under-filling costs more than over-filling
         score -= busy < target_waves ? 3.0 * (1.0 - busy / target_waves) : 0.25 * (busy / target_waves - 1.0);
@@ -965,7 +967,7 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
              a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
              s.mt, s.nt, s.wn, s.wk, s.d, am_rows(s.am), solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
              64 * s.wn * s.wk);
-    if (s.wm == 2)
+    if (s.wm == 2 && s.am < kDecodeAm) // (the 8-row decode kernel also carries warp_partition_m = 2: solution.h)
         strncat(buf, " shared-a", len - strlen(buf) - 1);
     if (s.am >= kDecodeAm)
         strncat(buf, " scale-after-mfma", len - strlen(buf) - 1);

@@ -36,7 +36,7 @@
 //                                 tile_m = MB (m32-blocks), bits 52-55 = 2 NP;
 //                                 13 = the 32x32x64 native-FP4 kernel (gemm_native32.hpp);
 //                                 4 / 14 / 15 = the NVFP4 decode kernel that scales after the
-//                                 MFMA (gemm_decode.hpp), 1 / 2 / 4 activation rows
+//                                 MFMA (gemm_decode.hpp), 1 / 2 / 4 activation rows (15 with warp_partition_m = 2: 8 rows)
 //   bits 52-55  [was padding]     NT  n-tiles per wave
 //   bits 56-59  [was padding]     D   W ring depth (tiles in flight per n-tile)
 //   bits 60-63  [was padding]     split-K across workgroups (gridDim.z), >= 1
@@ -74,8 +74,9 @@ constexpr bool is_native_am(int am) { return am == kNativeAm || am == kNative32A
 // am 101 / 102 / 104: staged activations (1 / 2 / 4 rows) converted to the fp16 pipeline with
 // per-span block floating point (Bf16Bfp in gemm_stream.hpp); codes 5 / 6 / 7
 constexpr int kBfpAm = 100;
-// am 201 / 202 / 204: the NVFP4 decode kernel with the group scale applied after the MFMA (gemm_decode.hpp), holding
-// 1 / 2 / 4 activation rows; codes 4 / 14 / 15
+// am 201 / 202 / 204 / 208: the NVFP4 decode kernel with the group scale applied after the MFMA (gemm_decode.hpp), holding
+// 1 / 2 / 4 / 8 activation rows; codes 4 / 14 / 15 / 15 (the 16 codes of the nibble are taken: the 8-row form is code 15 with
+// warp_partition_m = 2)
 constexpr int kDecodeAm = 200;
 constexpr int am_rows(int am) { return am >= kDecodeAm ? am - kDecodeAm : am >= kBfpAm ? am - kBfpAm : am; }
 constexpr unsigned am_code(int am) {

@@ -80,7 +80,9 @@ void tune_bucket(unsigned m, uint64_t solution, unsigned *m_lo, unsigned *m_hi) 
         lo = 257, hi = 1u << 20;
     // a kernel that stages at most AM activation rows cannot serve a bucket that reaches past AM: the row covers m alone
     static const int kRowsOfCode[16] = {0, 1, 2, 4, 1, 1, 2, 4, 0, 0, 8, 16, 0, 0, 2, 4};
-    const int rows = kRowsOfCode[(solution >> 48) & 0xf];
+    int rows = kRowsOfCode[(solution >> 48) & 0xf];
+    if (((solution >> 48) & 0xf) == 15 && ((solution >> 36) & 0xf) == 2)
+        rows = 8; // the 8-row decode kernel (solution.h)
     if (rows && (unsigned)rows < hi)
         lo = hi = m;
     *m_lo = lo, *m_hi = hi;
