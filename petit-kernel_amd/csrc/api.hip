@@ -465,9 +465,11 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         const bool is_ref = !have_ref && (klass == kClassExact ? (s.am == 0 && s.wm == 1 && s.pa == 1) : true);
         have_ref |= is_ref;
         push(e, 1, is_ref);
-        // K splits: the large-M kernels and the direct-path streaming kernel take any split; the staged / decode / shared-tile
-        // kernels none (one workgroup column walks all of K)
-        const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am == 0 && s.wm == 1);
+        // K splits: the large-M kernels and the streaming kernels (direct and staged) take any split; the decode / shared-tile
+        // kernels none
+        // (measured: down 8192 x 28672 at M = 16, staged 16 x 64 tiles with a K split of 2: 29.0 us against 30.5 unsplit -- every CU
+        // then pulls half of the activations)
+        const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1);
         if (!splittable)
             continue;
         for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)
