@@ -237,7 +237,9 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     const int want_mt = 1;
     const int want_am = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16;
     const bool mid = m > 4; // 5..16
-    const int want_nt = m <= 2 ? 1 : (mid && ntiles >= 4u * arch.num_cus) ? 4 : 4u * ntiles >= 5u * arch.num_cus ? 2 : 1;
+    // workgroup width: the widest of 16 / 32 / 64 columns that still leaves >= ~0.6 workgroups per CU (every swept winner at M = 5..16:
+    // N = 4096 -> 16, 6144..8192 -> 32, 10240..28672 -> 64 columns; a wider tile shares the activation block among more columns)
+    const int want_nt = m <= 2 ? 1 : (mid && 5u * ntiles >= 12u * arch.num_cus) ? 4 : 4u * ntiles >= 5u * arch.num_cus ? 2 : 1;
     const double target_waves = (double)arch.num_cus * (mid ? 4 : m > 2 ? 8 : 16);
     const SolutionEntry *best = nullptr;
     double best_score = -1e30;

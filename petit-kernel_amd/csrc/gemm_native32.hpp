@@ -247,13 +247,18 @@ template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, in
     static constexpr int kDataU4 = BM * kRowU4;               // one tile image
     static constexpr int kScaleU4 = (BM + 3) / 4 < kWaves * 16 ? kWaves * 16 : (BM + 3) / 4; // one dword per row (wave-loads of 64)
     static constexpr int kRowsPerLoad = 64 / kRowU4;          // rows one 1 KiB wave-load covers: 8 / 16
-    static constexpr int kDataLoads = BM / kRowsPerLoad / kWaves;
+    // waves that stage the activation tile: all of them when they divide its wave-loads, else four (five-wave workgroups: 160- and 320-column
+    // tiles put N = 10240 on the chip in ONE round of 256 workgroups where 128-column tiles need 1.25); the others issue the same number of
+    // loads, out of range, into a dump slot behind the stage (loads retire in order: every wave counts the same)
+    static constexpr int kDmaWaves = (BM / kRowsPerLoad) % kWaves == 0 ? kWaves : 4;
+    static constexpr int kDumpU4 = kDmaWaves < kWaves ? 64 : 0;
+    static constexpr int kDataLoads = BM / kRowsPerLoad / kDmaWaves;
     static_assert(ACT == 8 || ACT == 4, "activations are quantised to MXFP8 or MXFP4");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(WM == 1 || WM == 2, "one or two waves along M");
-    static_assert(BM % (kRowsPerLoad * kWaves) == 0 && BM <= 64 * kWaves, "A tile must split evenly over the waves");
-    static_assert((kRowsPerLoad * kWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
-    static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4);   // one stage: KT tile images, then their KT scale arrays
+    static_assert(BM % (kRowsPerLoad * kDmaWaves) == 0 && BM <= 64 * kWaves, "A tile must split evenly over the staging waves");
+    static_assert((kRowsPerLoad * kDmaWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
+    static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4) + kDumpU4;   // one stage: KT tile images, then their KT scale arrays (+ dump slot)
     static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
     static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && PF >= 1 && PF <= 3, "stage = 1 or 2 k-tiles, 1 to 3 stages ahead");
     static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
@@ -354,19 +359,23 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     // 128 / 64 bytes); lane l -> row + l / U, position l % U, which receives unit (l % U) ^ swz(row), U = 8 / 4 units per row,
     // swz(row) = (row / 2) % 8 resp. (row / 4) % 4: the 16 lanes of a ds_read_b128 group then hit 16 different 16-byte slots.
     constexpr unsigned U = Cfg::kRowU4, RPL = Cfg::kRowsPerLoad;
+    constexpr int kDmaWaves = Cfg::kDmaWaves;
+    const bool dma_wave = kDmaWaves == kWaves || wave < (unsigned)kDmaWaves;
     const unsigned dma_row0 = wave * RPL + lane / U;
     auto swz = [](unsigned row) -> unsigned { return ACT == 8 ? (row >> 1) & 7u : (row >> 2) & 3u; };
-    const unsigned dma_voff = dma_row0 * kRowB + (((lane % U) ^ swz(dma_row0)) * 16);
+    const unsigned dma_voff = dma_wave ? dma_row0 * kRowB + (((lane % U) ^ swz(dma_row0)) * 16) : kOob;
     const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * 4 : kOob;
     auto dma_stage = [&](unsigned kt, unsigned buf) { // k-tiles kt .. kt + KT - 1 -> stage `buf`
 #if defined(__HIP_DEVICE_COMPILE__) && !(PETIT_ABLATE_N32 & 1)
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
             u32x4 *const data = smem_g + buf * Cfg::kStageU4 + t * Cfg::kDataU4;
+            // (a wave that does not stage writes its zeros -- out-of-range loads -- into the stage's dump slot)
+            u32x4 *const dump = smem_g + buf * Cfg::kStageU4 + KT * (Cfg::kDataU4 + Cfg::kScaleU4);
 #pragma unroll
             for (int i = 0; i < Cfg::kDataLoads; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + (i * kWaves + wave) * 64), 16,
-                                                         dma_voff, i * (RPL * kWaves) * kRowB + (kt + t) * qa_tile, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(dma_wave ? data + (i * kDmaWaves + wave) * 64 : dump), 16,
+                                                         dma_voff, i * (RPL * kDmaWaves) * kRowB + (kt + t) * qa_tile, 0, 0);
             u32x4 *const sc = smem_g + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, (kt + t) * qs_tile, 0, 0);
         }
