@@ -1800,3 +1800,62 @@ def test_grouped_launch(pk, kind, is_bf16, m):
     big = torch.zeros((17, k), dtype=dtype, device=DEV)
     with pytest.raises(RuntimeError):
         pk.mul_fp4_a16_grouped(name, big, members, 17, k, -1)                       # not the decode regime
+
+
+def test_stacked_mlp_accuracy_budget(pk):
+    """The same budget through a STACK: four pre-norm residual MLP layers x <- x + down(silu_mul(gate_up(rmsnorm(x)))), hidden 1024,
+    intermediate 2048, 64 tokens, outlier channels in the residual stream (four columns x 40), fresh MXFP4 weights per layer.  The norm and the
+    residual run in torch fp32 (not this library's business); the three GEMM paths are the exact default, the native MXFP8 pipeline and the
+    native MXFP4 pipeline.  Reported: rms error of the final residual stream against the f64 oracle of the whole stack, relative to its rms --
+    how the per-GEMM activation-quantisation error accumulates over depth when a residual path carries the signal."""
+    import json
+    hid, inter, m, layers = 1024, 2048, 64, 4
+    rng = np.random.default_rng(77)
+    x0 = rng.standard_normal((m, hid)).astype(np.float32)
+    x0[:, rng.choice(hid, 4, replace=False)] *= 40.0
+    ws = []
+    for layer in range(layers):
+        _, q1, s1, _ = random_problem("mx", 1, 2 * inter, hid, 500 + layer, True, mx_band=(123, 127))
+        _, q2, s2, _ = random_problem("mx", 1, hid, inter, 600 + layer, True, mx_band=(123, 127))
+        ws.append((q1, s1, q2, s2))
+    gs1, gs2 = 0.05, 0.02
+
+    def rmsnorm(x):
+        return x / np.sqrt((x * x).mean(axis=1, keepdims=True) + 1e-6)
+
+    ref = x0.astype(np.float64)
+    for q1, s1, q2, s2 in ws:
+        y = rmsnorm(ref) @ O.dequant_mxfp4(q1, s1).astype(np.float64).T * gs1
+        h = y[:, :inter] / (1.0 + np.exp(-y[:, :inter])) * y[:, inter:]
+        ref = ref + h @ O.dequant_mxfp4(q2, s2).astype(np.float64).T * gs2
+    g1, g2 = torch.tensor([gs1], device=DEV), torch.tensor([gs2], device=DEV)
+    packed = []
+    for q1, s1, q2, s2 in ws:
+        packed.append((pk.repack_mxfp4(torch.from_numpy(q1).to(DEV).view(torch.int32), 2 * inter, hid), pk.process_mxfp4_scales(torch.from_numpy(s1).to(DEV), 2 * inter, hid),
+                       pk.repack_mxfp4(torch.from_numpy(q2).to(DEV).view(torch.int32), hid, inter), pk.process_mxfp4_scales(torch.from_numpy(s2).to(DEV), hid, inter)))
+    report = {}
+    for name in ("exact", "mxfp8", "mxfp4"):
+        x = torch.from_numpy(x0).to(DEV)                                  # residual stream in fp32
+        for b1, sp1, b2, sp2 in packed:
+            xn = (x / torch.sqrt((x * x).mean(dim=1, keepdim=True) + 1e-6)).bfloat16()
+            if name == "exact":
+                h = pk.mul_mxfp4_a16(xn, b1, sp1, g1, m, 2 * inter, hid, -1, activation="silu_mul")
+                d = pk.mul_mxfp4_a16(h, b2, sp2, g2, m, hid, inter, -1)
+            else:
+                sid = pk.SOLUTION_AUTO_NATIVE_MXFP8 if name == "mxfp8" else pk.SOLUTION_AUTO_NATIVE_MXFP4
+                hq = pk.mul_mxfp4_native(pk.quantize_activations(xn, name), b1, sp1, g1, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=name)
+                d = pk.mul_mxfp4_native(hq, b2, sp2, g2, m, hid, inter, sid)
+            x = x + d.float()
+        e = x.cpu().numpy().astype(np.float64) - ref
+        # the update the four layers added (the residual stream itself is dominated by x0, which every path carries exactly)
+        upd = ref - x0
+        report[name] = {"rms_err_over_rms_of_stream": float(np.sqrt(np.mean(e ** 2)) / np.sqrt(np.mean(ref ** 2))),
+                        "rms_err_over_rms_of_update": float(np.sqrt(np.mean(e ** 2)) / np.sqrt(np.mean(upd ** 2)))}
+    print("stacked mlp accuracy budget:", json.dumps(report))
+    dump = ROOT / "gpurun_out"
+    if dump.is_dir():
+        (dump / "stacked_mlp_accuracy_budget.json").write_text(json.dumps({"layers": layers, "hidden": hid, "intermediate": inter, "m": m,
+                                                                           "outlier_columns": 4, "outlier_factor": 40, "errors": report}, indent=1))
+    assert report["exact"]["rms_err_over_rms_of_update"] <= 2e-2
+    assert report["mxfp8"]["rms_err_over_rms_of_update"] <= 0.15
+    assert report["mxfp4"]["rms_err_over_rms_of_update"] <= 0.8
