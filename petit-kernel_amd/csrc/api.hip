@@ -949,10 +949,10 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kOk;
     }
     if (s.am == kNative32Am) {
-        const int wm = s.wm == 2 ? 2 : 1, kgrp = s.wm == 3 ? 2 : 1;
-        snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, s.d,
-                 s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * wm * kgrp);
+        const int wm = s.wm == 2 ? 2 : 1, kgrp = s.wm == 3 ? 2 : 1, lw = s.wm == 4 ? 1 : 0;
+        snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d%s d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, lw ? " +loader" : "", s.d,
+                 s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * (s.wn * wm * kgrp + lw));
         return kOk;
     }
     if (s.am == kWideAm) {

@@ -236,12 +236,20 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
 //        through LDS before the epilogue.  Two waves per SIMD that share NOTHING (WM = 2 shares the weight tiles and lost): what a
 //        second workgroup on the CU gives the 128 x 256 kernel, for shapes whose grid is only one 128 x 128 tile per CU (N <= 10240
 //        at M = 512: `o`, qkv).
-template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1, int KG_ = 1> struct Native32Cfg {
+//   LW   1: a LOADER wave.  Loads retire in issue order, so a wave that issues both the weight refills (first touch of a panel: an HBM /
+//        Infinity-Cache miss, ~2 us) and the activation-tile DMA (an L2 hit, ~0.4 us) waits for the misses whenever it waits for the tile, whatever
+//        the ring depth: every large-M kernel of this repo pulled its operands at ~12 TB/s, a third of what L2 delivers (tools/probes/l2_ingest.hip:
+//        28-36 TB/s from an L2-resident window at the same bytes in flight).  With LW the activation tiles are staged by one extra wave whose queue
+//        holds nothing else; the compute waves issue weight loads only and meet the loader at the stage barrier.
+template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1, int KG_ = 1, int LW_ = 0>
+struct Native32Cfg {
     using AT = AT_;
     static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, PF = PF_, NBUF = PF_ + 1;
-    static constexpr int WM = WM_, kWaves = WAVES * WM, KG = KG_;
-    static constexpr int kThreads = 64 * kWaves * KG;
+    static constexpr int WM = WM_, kWaves = WAVES * WM, KG = KG_, LW = LW_;
+    static constexpr int kComputeThreads = 64 * kWaves * KG;
+    static constexpr int kThreads = kComputeThreads + 64 * LW;
     static_assert(KG == 1 || (KG == 2 && WM == 1), "two K groups only with one wave along M");
+    static_assert(LW == 0 || (LW == 1 && KG == 1 && WM == 1 && PF_ >= 2), "the loader wave: one K group, stages in flight across the barrier");
     static constexpr int BM = 32 * MB * WM;
     static constexpr int kRowU4 = ACT;                        // 16-byte units per LDS row: 128 B (FP8) / 64 B (FP4)
     static constexpr int kDataU4 = BM * kRowU4;               // one tile image
@@ -404,11 +412,59 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 
     // --- prologue: stage 0 (and 1 when two are kept ahead), scale records, the W ring
     const unsigned kt_end = sp_end * KS;
-    dma_stage(kt_begin, 0);
+    if constexpr (Cfg::LW) {
+        if (wave_all == (unsigned)(kWaves * KG)) {
+            // The loader wave: stages every activation tile of the workgroup (all BM rows: BM / RPL wave-loads of 1 KiB + the scale dwords
+            // per k-tile), PF stages ahead, and executes exactly the barriers of the compute waves' main loop; then it is done.
+#if defined(__HIP_DEVICE_COMPILE__)
+            constexpr int kLdData = Cfg::BM / (int)RPL, kLdScale = (Cfg::BM + 63) / 64, kLdStage = KT * (kLdData + kLdScale);
+            unsigned lvoff[kLdData];
 #pragma unroll
-    for (int i = 1; i < PF; ++i)
-        if (kt_begin + i * KT < kt_end)
-            dma_stage(kt_begin + i * KT, i);
+            for (int i = 0; i < kLdData; ++i) {
+                const unsigned row = i * RPL + lane / U;
+                lvoff[i] = row * kRowB + (((lane % U) ^ swz(row)) * 16);
+            }
+            auto load_stage = [&](unsigned kt, unsigned buf) {
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    u32x4 *const data = smem + buf * Cfg::kStageU4 + t * Cfg::kDataU4;
+#pragma unroll
+                    for (int i = 0; i < kLdData; ++i)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(data + i * 64), 16, lvoff[i],
+                                                                 (kt + t) * qa_tile, 0, 0);
+                    u32x4 *const sc = smem + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
+#pragma unroll
+                    for (int j = 0; j < kLdScale; ++j)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + j * 16), 4,
+                                                                 (j * 64 + lane < (unsigned)Cfg::BM) ? (j * 64 + lane) * 4 : kOob, (kt + t) * qs_tile, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                load_stage(kt_begin + i * KT, i); // (past the K slice: out of the descriptor's range -- zeros into a stage nobody reads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // the compute waves' prologue barrier: stage 0 is complete and visible
+            const unsigned nstages = (sp_end - sp_begin) * (KS / KT);
+            unsigned buf = PF % NBUF;
+            for (unsigned st = 0; st < nstages; ++st) {
+                load_stage(kt_begin + (st + PF) * KT, buf);
+                buf = buf == (unsigned)(NBUF - 1) ? 0u : buf + 1;
+                if (st + 1 < nstages) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * kLdStage) : "memory"); // stage st + 1 has landed
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this wave lands in LDS after it is gone (the epilogue reuses the stages)
+#endif
+            return;
+        }
+    } else {
+        dma_stage(kt_begin, 0);
+#pragma unroll
+        for (int i = 1; i < PF; ++i)
+            if (kt_begin + i * KT < kt_end)
+                dma_stage(kt_begin + i * KT, i);
+    }
     ScaleRec<kFmtMx, KS> rec[NP][2], rec_next[NP][2];
     auto load_recs = [&](ScaleRec<kFmtMx, KS> (*dst)[2], unsigned sp) {
 #pragma unroll
@@ -448,7 +504,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             } else {
                 // always issued (beyond the K slice the loads are out of the descriptor's range: zeros into a stage nobody
                 // reads), so the wait below is one constant and there is no branch around the MFMA stream
-                dma_stage(kt + PF * KT, cur_buf == 0 ? (unsigned)(NBUF - 1) : cur_buf - 1);
+                if constexpr (!Cfg::LW)
+                    dma_stage(kt + PF * KT, cur_buf == 0 ? (unsigned)(NBUF - 1) : cur_buf - 1);
             }
             Frags fr[2];
             read_frags(stage, stage_sc, 0, fr[0]);
@@ -530,7 +587,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                         return (PETIT_ABLATE_N32 & 2) ? 0 : n;
                     }();
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * Cfg::kStageLoads + kPrevRefills) : "memory");
+                    if constexpr (!Cfg::LW) // (with a loader wave the compute waves wait for nothing here: the loader vouches for the stage)
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * Cfg::kStageLoads + kPrevRefills) : "memory");
                     __builtin_amdgcn_s_barrier();
 #endif
                 }
@@ -624,7 +682,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
         const unsigned n_half = p.n >> 1;
         if (KG == 2 && kg != 0)
             return;
-        if constexpr (NP == 2 && WM == 1 && WAVES == 4 && KG == 1) {
+        if constexpr (NP == 2 && WM == 1 && WAVES == 4 && KG == 1 && Cfg::LW == 0) {
             if (p.out_format) { // (workgroup-uniform) the launcher admits it for full 256-column tiles only: n % 512 == 0
                 __syncthreads(); // the stages are dead: their LDS holds the scale bytes of the tile
                 unsigned char *const lds_sc = reinterpret_cast<unsigned char *>(smem);
@@ -670,7 +728,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             }
     __syncthreads();
     const unsigned n0 = bn * Cfg::BN;
-    c_tile_store<Cfg::BM, Cfg::BN, Cfg::kThreads>(smem, p.c, p.n, m0, n0, rows, n0 < p.n ? min((unsigned)Cfg::BN, p.n - n0) : 0u, tid);
+    c_tile_store<Cfg::BM, Cfg::BN, Cfg::kComputeThreads>(smem, p.c, p.n, m0, n0, rows, n0 < p.n ? min((unsigned)Cfg::BN, p.n - n0) : 0u, tid);
 }
 
 } // namespace petit_amd

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/petit_amd.h"
@@ -238,10 +239,27 @@ void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const u
     rq.m = m, rq.n = n, rq.k = k, rq.a_type = a_type, rq.b_type = b_type, rq.klass = 0;
     rq.own_workspace = true, rq.stream = stream, rq.persist = true;
     rq.rotate_bytes = (size_t)384 << 20; // past the 256 MB Infinity Cache
+    // a problem whose tuning failed (out of device memory for the clones, a capture in progress on another stream of the graph, ...)
+    // is not retried on every call: remember its key for the life of the process
+    struct Key {
+        int a_type, b_type;
+        unsigned n, k, m_lo;
+    };
+    static std::mutex failed_mutex;
+    static std::vector<Key> failed;
+    unsigned lo, hi;
+    tune_bucket(m, 0, &lo, &hi);
+    {
+        std::lock_guard<std::mutex> lock(failed_mutex);
+        for (const Key &f : failed)
+            if (f.a_type == a_type && f.b_type == b_type && f.n == n && f.k == k && f.m_lo == lo)
+                return;
+    }
     uint64_t best = 0;
     float us = 0.f;
     if (tune_problem(rq, &best, &us) != kOk) {
-        // remember the failure as a row naming the heuristic's own pick would; simplest: nothing -- the next call tries again
+        std::lock_guard<std::mutex> lock(failed_mutex);
+        failed.push_back(Key{a_type, b_type, n, k, lo});
         return;
     }
     const char *path = getenv("PETIT_AMD_TUNE_FILE");
