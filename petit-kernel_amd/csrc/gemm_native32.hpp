@@ -425,6 +425,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 lvoff[i] = row * kRowB + (((lane % U) ^ swz(row)) * 16);
             }
             auto load_stage = [&](unsigned kt, unsigned buf) {
+                if constexpr (PETIT_ABLATE_N32 & 1)
+                    return;
 #pragma unroll
                 for (int t = 0; t < KT; ++t) {
                     u32x4 *const data = smem + buf * Cfg::kStageU4 + t * Cfg::kDataU4;

@@ -12,6 +12,6 @@ done
 wait
 for abl in "$@"; do
   hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/ablate/n32/libpetit_abl_$abl.so $R/tools/ablate/n32/mx_bf16_$abl.o \
-     build/api.o build/gemm_nv_f16.o build/gemm_nv_bf16.o build/gemm_mx_f16.o build/hal.o build/repack.o build/dequant.o
+     build/api.o build/tune.o build/gemm_nv_f16.o build/gemm_nv_bf16.o build/gemm_mx_f16.o build/hal.o build/repack.o build/dequant.o
 done
 ls -la $R/tools/ablate/n32/*.so
