@@ -35,3 +35,4 @@ extern "C" int ingest_launch(int u, const void *src, unsigned window_bytes, unsi
 #undef L
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
