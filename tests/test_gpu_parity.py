@@ -1859,3 +1859,13 @@ def test_stacked_mlp_accuracy_budget(pk):
     assert report["exact"]["rms_err_over_rms_of_update"] <= 2e-2
     assert report["mxfp8"]["rms_err_over_rms_of_update"] <= 0.15
     assert report["mxfp4"]["rms_err_over_rms_of_update"] <= 0.8
+
+
+def test_examples_run(pk):
+    """examples/fp4_linear.py and examples/mxfp4_mlp_pipeline.py run to completion on the GPU (their own assertions included)."""
+    import subprocess
+    import sys
+    for name in ("fp4_linear.py", "mxfp4_mlp_pipeline.py"):
+        out = subprocess.run([sys.executable, str(ROOT / "examples" / name)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "MISMATCH" not in out.stdout

@@ -496,3 +496,52 @@ def test_tune_params_struct_matches_the_header():
     names = [n.strip() for f in fields for n in f.split(",")]
     assert names == [f[0] for f in _lib.TuneParams._fields_]
     assert C.sizeof(_lib.TuneParams) == 64
+
+
+def test_new_entry_points_validate_before_they_launch():
+    """Argument checks of the round-3 entry points that need no GPU: every refusal happens before anything is enqueued."""
+    from petit_kernel import _lib
+    L = _lib.lib
+    fake = C.c_void_p(4096)                                   # never dereferenced: the checks come first
+    h_nv = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    h_mx = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    # grouped launch
+    mem = (_lib.GroupMember * 9)(*[_lib.GroupMember(4096, 4096, 4096, 4096, None, 256, 0) for _ in range(9)])
+    auto = C.c_uint64(_lib.PETIT_SOLUTION_AUTO)
+    assert L.petit_gemm_fp4_fp16_grouped(mem, 9, fake, 1, 1024, C.byref(h_nv), auto, None) == _lib.PETIT_ERROR_BAD_ARGUMENT      # > 8 members
+    assert L.petit_gemm_fp4_fp16_grouped(mem, 3, fake, 17, 1024, C.byref(h_nv), auto, None) == _lib.PETIT_ERROR_KERNEL_SHAPE      # not the decode regime
+    assert L.petit_gemm_fp4_fp16_grouped(mem, 3, fake, 1, 1000, C.byref(h_nv), auto, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE      # k % 256
+    assert L.petit_gemm_fp4_fp16_grouped(mem, 0, fake, 1, 1024, C.byref(h_nv), auto, None) == 0                                   # empty group: nothing to do
+    bad = (_lib.GroupMember * 1)(_lib.GroupMember(4096, None, 4096, 4096, None, 256, 0))
+    assert L.petit_gemm_fp4_fp16_grouped(bad, 1, fake, 1, 1024, C.byref(h_nv), auto, None) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    odd = (_lib.GroupMember * 1)(_lib.GroupMember(4096, 4096, 4096, 4096, None, 250, 0))
+    assert L.petit_gemm_fp4_fp16_grouped(odd, 1, fake, 1, 1024, C.byref(h_nv), auto, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE      # n % 16
+    # the native entry point
+    na = _lib.NativeArgs(C.sizeof(_lib.NativeArgs), 4, 0, 0)
+    call = lambda hints, sid, nargs, n=512, k=1024, epi=None, c=fake, a=fake: L.petit_gemm_mxfp4_native(
+        c, a, fake, fake, fake, 64, n, k, C.byref(hints), C.c_uint64(sid), epi, C.byref(nargs) if nargs is not None else None, None, C.c_uint64(0), None)
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO, na) == _lib.PETIT_ERROR_KERNEL_SHAPE                      # plain AUTO never enters the class
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, na) == _lib.PETIT_ERROR_KERNEL_SHAPE         # MXFP4-quantised input, MXFP8 class
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, _lib.NativeArgs(8, 4, 0, 0)) == _lib.PETIT_ERROR_BAD_ARGUMENT    # struct size
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, _lib.NativeArgs(16, 5, 0, 0)) == _lib.PETIT_ERROR_BAD_ARGUMENT   # unknown format
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, _lib.NativeArgs(16, 0, 4, 0)) == _lib.PETIT_ERROR_BAD_ARGUMENT   # quantised output without SiLU-mul
+    epi = _lib.Epilogue(None, 1, 0)
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, _lib.NativeArgs(16, 0, 4, 0), n=768, epi=C.byref(epi)) == _lib.PETIT_ERROR_PROBLEM_SHAPE  # n % 512
+    assert call(h_mx, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, na, a=C.c_void_p(4100)) == _lib.PETIT_ERROR_BAD_ARGUMENT         # misaligned quantised input
+    # sizes of the quantised-activation format
+    assert L.petit_quantized_activation_bytes(512, 8192, 4) == 512 * 8192 // 2 + 512 * 8192 // 32
+    assert L.petit_quantized_activation_bytes(512, 8192, 8) == 512 * 8192 + 512 * 8192 // 32 == L.petit_native_workspace_bytes(512, 8192)
+    assert L.petit_quantized_activation_bytes(512, 8192, 6) == 0
+    assert L.petit_quantize_activations(fake, fake, 4, 1000, _lib.CXX_DTYPE_BF16, 4, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
+    assert L.petit_quantize_activations(fake, fake, 4, 1024, 3, 4, None) == _lib.PETIT_ERROR_KERNEL_SHAPE                   # not a 16-bit activation type
+    assert L.petit_quantize_activations(None, fake, 4, 1024, _lib.CXX_DTYPE_BF16, 4, None) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    # the scratch a pipeline call needs: with quantised input only the slabs of a K split remain
+    full = L.petit_gemm_native_workspace_bytes(C.byref(h_mx), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), None, None)
+    pre = L.petit_gemm_native_workspace_bytes(C.byref(h_mx), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), None, C.byref(na))
+    assert full >= 512 * 8192 // 2 and pre < 512 * 8192 // 2
+    # the tuner
+    tp = _lib.TuneParams(8, 0, 1, 0, None, None, 0, 0, 0.0, 0, 0, 0, 0)
+    best, us = C.c_uint64(0), C.c_float(0)
+    assert L.petit_gemm_tune(fake, fake, fake, 16, 512, 1024, C.byref(h_nv), C.byref(tp), None, C.c_uint64(0), None, C.byref(best), C.byref(us)) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    tp = _lib.TuneParams(C.sizeof(_lib.TuneParams), 3, 1, 0, None, None, 0, 0, 0.0, 0, 0, 0, 0)                              # unknown class
+    assert L.petit_gemm_tune(fake, fake, fake, 16, 512, 1024, C.byref(h_nv), C.byref(tp), None, C.c_uint64(0), None, C.byref(best), C.byref(us)) == _lib.PETIT_ERROR_BAD_ARGUMENT
