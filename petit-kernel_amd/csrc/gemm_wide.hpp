@@ -75,20 +75,26 @@ __device__ __forceinline__ void merge_tiles(unsigned x, unsigned y, unsigned &p1
 //         the same 70 us at M = 512, N = K = 8192); 2 = three LDS buffers, the tile of step t + 2 is requested at the
 //         top of step t and stays in flight across the barrier (raw s_barrier + counted vmcnt: __syncthreads() would
 //         drain it), two steps of cover.
-template <class AT_, int FMT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int PF_ = 1> struct WideCfg {
+//   KG    wave GROUPS along K inside the workgroup (1 or 2), as Native32Cfg (gemm_native32.hpp): two complete copies of the wave set, each with its
+//         own LDS buffers and weight ring, half of the workgroup's K range each, accumulators summed through LDS before the epilogue -- two waves
+//         per SIMD for grids of ONE 128 x 128 tile per CU (`o`, qkv at M = 512), where gate_up gets them from two resident workgroups.
+template <class AT_, int FMT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int PF_ = 1, int KG_ = 1> struct WideCfg {
     using AT = AT_;
-    static constexpr int FMT = FMT_, KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, PF = PF_, NBUF = PF_ + 1;
-    static constexpr int kThreads = 64 * WAVES;
-    static constexpr int BM = 32 * MB;
+    static constexpr int FMT = FMT_, KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, PF = PF_, NBUF = PF_ + 1, KG = KG_;
+    static constexpr int kThreads = 64 * WAVES * KG;
+    static constexpr int BM = 32 * MB, BN = 32 * NP * WAVES;
     static constexpr int kBufU4 = BM * 16;                  // one A tile: BM rows x 16 units of 16 B, XOR-swizzled
     static constexpr int kDmaLoads = BM * 16 / 64 / WAVES;  // 1 KiB wave-loads per wave per tile
     // 64 accumulator registers per wave leave room for two waves per SIMD (two workgroups per CU)
-    static constexpr int kMinWavesPerSimd = (NP == 1 && MB <= 4 && PF == 1) ? 2 : 1; // (NP = 2 doubles the unpacked-fragment sets)
+    static constexpr int kMinWavesPerSimd = (KG == 2 || (NP == 1 && MB <= 4 && PF == 1)) ? 2 : 1; // (NP = 2 doubles the unpacked-fragment sets)
+    static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;  // KG = 2: the second group's accumulators, f32
+    static constexpr int kSmemU4 = KG * NBUF * kBufU4 > kRedU4 ? KG * NBUF * kBufU4 : kRedU4;
+    static_assert(KG == 1 || KG == 2, "one or two K groups");
     static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2");
     static_assert(!AT::kSplit && !AT::kBfp, "plain 16-bit activations only");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert((BM * 16) % (64 * WAVES) == 0 && (4 * WAVES) % 16 == 0, "A tile must split into whole 16-row groups per wave-load");
-    static_assert(NBUF * kBufU4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
 };
 
 template <class Cfg>
@@ -101,11 +107,15 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
     constexpr int kRecDw = ScaleRec<FMT, KS>::kDwords;
     constexpr unsigned kOob = 0x80000000u;
 
-    __shared__ u32x4 smem[NBUF * Cfg::kBufU4];
+    constexpr int KG = Cfg::KG;
+    __shared__ u32x4 smem_all[Cfg::kSmemU4];
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63u;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned kg = KG == 1 ? 0u : wave_all / WAVES;           // K group of this wave
+    const unsigned wave = KG == 1 ? wave_all : wave_all % WAVES;   // index inside the group
+    u32x4 *const smem = smem_all + kg * (NBUF * Cfg::kBufU4);      // this group's A-tile buffers
     const unsigned m_l = lane & 31u, h = lane >> 5; // fragment row (activation row / weight row of the pair), k-half
 
     const unsigned ktiles = p.k / kTileK;
@@ -116,7 +126,10 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
     stagger_priority(p.flags);
     const unsigned nt0 = (bn * WAVES + wave) * (2 * NP); // first logical n-tile of this wave
     const unsigned m0 = bm * Cfg::BM;
-    const unsigned sp_begin = min(blockIdx.z * p.spans_per_wave, nspans - 1);
+    // K slice of this wave group: part blockIdx.z * KG + kg (gemm_native32.hpp: a part past the end walks the last span with its weight rows masked)
+    const unsigned part_begin = (blockIdx.z * KG + kg) * p.spans_per_wave;
+    const bool empty_part = KG == 2 && part_begin >= nspans;
+    const unsigned sp_begin = min(part_begin, nspans - 1);
     const unsigned sp_end = min(sp_begin + p.spans_per_wave, nspans);
     const unsigned kt_begin = sp_begin * KS;
 
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
             for (int v = 0; v < 16; ++v)
                 acc[mb][np][v] = 0.f;
 
-    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)(2 * NP), ntiles - nt0) : 0u;
+    const unsigned valid_nt = (nt0 < ntiles && !empty_part) ? min((unsigned)(2 * NP), ntiles - nt0) : 0u;
     const unsigned w_row_bytes = ktiles * kTileBytes;
     const unsigned s_row_bytes = (FMT == kFmtNv) ? p.k : p.k / 2;
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
@@ -346,6 +359,35 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
     for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
         span_body(sp, std::false_type{});
     span_body(sp_end - 1, std::true_type{});
+
+    if constexpr (KG == 2) {
+        // a group with fewer spans than its partner keeps the partner's barrier count (a span is KS barriers: the prologue's stands in for
+        // the one the last step does not execute), then group 1 parks its accumulators in LDS and group 0 adds them (gemm_native32.hpp)
+        for (unsigned i = sp_end - sp_begin; i < p.spans_per_wave; ++i)
+            for (int b = 0; b < KS; ++b)
+                __builtin_amdgcn_s_barrier();
+        __syncthreads();
+        float *const red = reinterpret_cast<float *>(smem_all);
+        if (kg == 1) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        red[(((wave * MB + mb) * NP + np) * 16 + v) * 64 + lane] = acc[mb][np][v];
+        }
+        __syncthreads();
+        if (kg == 1)
+            return;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    acc[mb][np][v] += red[(((wave * MB + mb) * NP + np) * 16 + v) * 64 + lane];
+    }
 
     // --- epilogue.  32x32 accumulator: lane (m = l%32, h = l/32) holds, for v = 4u + e, row n = 8u + 4h + e of the
     // pair's 32 weight rows: four groups of 4 consecutive n (rows 0-15 = first tile of the pair, 16-31 = second).
