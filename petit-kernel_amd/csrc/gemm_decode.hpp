@@ -56,9 +56,11 @@ template <class AT_, int KS_, int NT_, int WK_, int D_, int R_> struct DecodeCfg
     static constexpr int kThreads = 64 * WK;
     static constexpr int TG = (R == 1) ? 2 : 1;           // k-tiles per D tile
     static constexpr int kARowU4 = KS * 16 + 1;           // one staged row (padded: rows land on different banks)
-    static constexpr int kALdsU4 = (R + 1) * kARowU4;     // R rows + the zero row, per wave
+    static constexpr int kALdsU4 = R * kARowU4;           // R rows per wave; ONE zero row for the whole workgroup behind them (every wave
+                                                          // writes the same zeros before it reads them: no barrier; at R = 4, WK = 8 the
+                                                          // private zero rows were what kept a second workgroup off the CU: 85 -> 70 KiB)
     static constexpr int kRedFloats = NT * R * 16;        // per wave: y[nt][m][n % 16]
-    static constexpr int kSmemU4 = WK * kALdsU4 + WK * kRedFloats / 4;
+    static constexpr int kSmemU4 = WK * kALdsU4 + kARowU4 + WK * kRedFloats / 4;
     static constexpr int kAStageU4 = R * KS * 16;         // one span of A, in 16-byte units
     static constexpr int kAStageLoads = (kAStageU4 + 63) / 64;
     // resident waves per SIMD the register allocation must allow: four for one n-tile per wave (two 512-thread or four
@@ -203,11 +205,12 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
             for (int nt = 0; nt < NT; ++nt)
                 wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxNt);
 
-        // the zero row (slot R of the slice), written once: the 128 slots the masked reads can touch
+        // the workgroup's zero row, written (redundantly, by every wave) once: the 128 slots the masked reads can touch
+        u32x4 *const zero_row = smem + WK * Cfg::kALdsU4;
 #pragma unroll
         for (int i = 0; i < KS * 16; i += 64)
             if (KS * 16 - i >= 64 || lane < (unsigned)(KS * 16 - i))
-                (a_lds + lane)[R * Cfg::kARowU4 + i] = u32x4{0, 0, 0, 0};
+                (zero_row + lane)[i] = u32x4{0, 0, 0, 0};
 
         // Fragment pointers: lane (g, rho = r) of the activation operand reads data for the MFMAs whose D row it owns
         // and the zero row for all others.  kBases distinct (tile parity, j >> 1) classes; everything else about a
@@ -221,7 +224,7 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
         for (int c = 0; c < kBases; ++c) {
             // R = 8: base c = pass (set) c; this lane's operand is live in the pass that covers its lane group, for the class its D row names
             const bool live = R == 8 ? ((g >> 1) == (unsigned)c && (g & 1u) == (r >> 3)) : (mine && key == (unsigned)c);
-            fbase[c] = a_lds + (int)((live ? row : (unsigned)R) * Cfg::kARowU4 + g * 4);
+            fbase[c] = (live ? a_lds + (int)(row * Cfg::kARowU4) : zero_row) + (int)(g * 4);
         }
 
         write_a_stage();
@@ -350,7 +353,7 @@ __device__ __forceinline__ void gemm_decode_body(const void *arg_w, const void *
     }
 
     // --- y[m][n] of this wave: fold the D rows, sum the four lane rows, park in LDS ------------------------------
-    float *const red = reinterpret_cast<float *>(smem + WK * Cfg::kALdsU4);
+    float *const red = reinterpret_cast<float *>(smem + WK * Cfg::kALdsU4 + Cfg::kARowU4);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         if constexpr (R == 8) {
