@@ -236,18 +236,32 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
 //        through LDS before the epilogue.  Two waves per SIMD that share NOTHING (WM = 2 shares the weight tiles and lost): what a
 //        second workgroup on the CU gives the 128 x 256 kernel, for shapes whose grid is only one 128 x 128 tile per CU (N <= 10240
 //        at M = 512: `o`, qkv).
-//   LW   1: a LOADER wave.  Loads retire in issue order, so a wave that issues both the weight refills (first touch of a panel: an HBM /
-//        Infinity-Cache miss, ~2 us) and the activation-tile DMA (an L2 hit, ~0.4 us) waits for the misses whenever it waits for the tile, whatever
-//        the ring depth: every large-M kernel of this repo pulled its operands at ~12 TB/s, a third of what L2 delivers (tools/probes/l2_ingest.hip:
-//        28-36 TB/s from an L2-resident window at the same bytes in flight).  With LW the activation tiles are staged by one extra wave whose queue
-//        holds nothing else; the compute waves issue weight loads only and meet the loader at the stage barrier.
+//   LW   1: a LOADER wave: the activation tiles are staged by one extra wave whose queue holds nothing else; the compute waves issue weight loads
+//        only and meet the loader at the stage barrier.  Built on the hypothesis that hits queue behind misses (loads retire in issue order); worth
+//        4-13 % at M = 512, but the hypothesis itself did not survive the follow-up experiments (PETIT_N32_PW / PETIT_N32_LWPF below,
+//        profiles/r03_native_ablation.md): a CU takes in ~60-65 GB/s of this kind of stream however it is requested.
 template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1, int KG_ = 1, int LW_ = 0>
 struct Native32Cfg {
     using AT = AT_;
-    static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, PF = PF_, NBUF = PF_ + 1;
+#ifndef PETIT_N32_LWPF
+#define PETIT_N32_LWPF 0
+#endif
+    static constexpr int kLwStageLoads = KT_ * (32 * MB_ * WM_ * ACT_ / 64 + (32 * MB_ * WM_ + 63) / 64); // wave-loads of the loader per stage
+    static constexpr int kLwPfMax = 1 + 63 / kLwStageLoads;                                              // (vmcnt counts to 63)
+    static constexpr int PF = (LW_ && PETIT_N32_LWPF) ? (PETIT_N32_LWPF < kLwPfMax ? PETIT_N32_LWPF : kLwPfMax) : PF_; // (experiment: deeper activation staging)
+    static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, NBUF = PF + 1;
     static constexpr int WM = WM_, kWaves = WAVES * WM, KG = KG_, LW = LW_;
     static constexpr int kComputeThreads = 64 * kWaves * KG;
-    static constexpr int kThreads = kComputeThreads + 64 * LW;
+#ifndef PETIT_N32_PW
+#define PETIT_N32_PW 0
+#endif
+#ifndef PETIT_N32_PWSHARE
+#define PETIT_N32_PWSHARE 1
+#endif
+    // PW (experiment, with LW): a PREFETCH wave that touches the workgroup's weight lines PETIT_N32_PW k-tiles ahead (one dword per 128-byte line, into
+    // an LDS dump slot), so that the compute waves' refills find them in L2
+    static constexpr int PW = (LW_ && PETIT_N32_PW) ? 1 : 0;
+    static constexpr int kThreads = kComputeThreads + 64 * (LW + PW);
     static_assert(KG == 1 || (KG == 2 && WM == 1), "two K groups only with one wave along M");
     static_assert(LW == 0 || (LW == 1 && KG == 1 && WM == 1 && PF_ >= 2), "the loader wave: one K group, stages in flight across the barrier");
     static constexpr int BM = 32 * MB * WM;
@@ -268,7 +282,7 @@ struct Native32Cfg {
     static_assert((kRowsPerLoad * kDmaWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
     static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4) + kDumpU4;   // one stage: KT tile images, then their KT scale arrays (+ dump slot)
     static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
-    static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && PF >= 1 && PF <= 3, "stage = 1 or 2 k-tiles, 1 to 3 stages ahead");
+    static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && PF >= 1 && (PF <= 3 || LW_), "stage = 1 or 2 k-tiles, 1 to 3 stages ahead");
     static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
     static constexpr int BN = 32 * NP * WAVES;
     // 128 x 256 / 256 x 128 with a two-tile ring: asked to fit two workgroups per CU (256 registers, 128 of them accumulators):
@@ -277,7 +291,7 @@ struct Native32Cfg {
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
     static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;       // KG = 2: the second group's accumulators, f32
     static constexpr int kSmemU4a = KG * NBUF * kStageU4 > kCTileU4 ? KG * NBUF * kStageU4 : kCTileU4;
-    static constexpr int kSmemU4 = kSmemU4a > kRedU4 ? kSmemU4a : kRedU4;
+    static constexpr int kSmemU4 = (kSmemU4a > kRedU4 ? kSmemU4a : kRedU4) + 16 * PW;
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
 };
 
@@ -459,6 +473,46 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this wave lands in LDS after it is gone (the epilogue reuses the stages)
 #endif
             return;
+        }
+        if constexpr (Cfg::PW) {
+            if (wave_all == (unsigned)(kWaves * KG + 1)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                constexpr int kPwTiles = 2 * NP * WAVES, kPwLoads = (kPwTiles * 8 + 63) / 64, kAhead = PETIT_N32_PW;
+                const unsigned nt0_wg = bn * WAVES * (2 * NP);
+                const unsigned valid_wg = nt0_wg < ntiles ? min((unsigned)kPwTiles, ntiles - nt0_wg) : 0u;
+                const unsigned pt0_wg = valid_wg ? physical_tile(nt0_wg, ntiles, p.act) : 0u;
+                const unsigned span_wg = !valid_wg ? 0u : p.act ? (valid_wg >> 1) + (ntiles >> 1) : valid_wg;
+                const __amdgpu_buffer_rsrc_t pw_rsrc = make_rsrc((const char *)p.w + (size_t)pt0_wg * w_row_bytes, span_wg * w_row_bytes);
+                u32x4 *const pw_dump = smem + (Cfg::kSmemU4 - 16);
+                unsigned pvoff[kPwLoads];
+#pragma unroll
+                for (int j = 0; j < kPwLoads; ++j) {
+                    const unsigned idx = j * 64 + lane, t = idx / 8, line = idx % 8;
+                    const bool mine = PETIT_N32_PWSHARE == 1 || (idx % PETIT_N32_PWSHARE) == (bm % PETIT_N32_PWSHARE);
+                    pvoff[j] = (t < valid_wg && mine) ? (physical_tile(nt0_wg + t, ntiles, p.act) - pt0_wg) * w_row_bytes + line * 128 : kOob;
+                }
+                auto prefetch = [&](unsigned kt) {
+                    if (kt < kt_end) {
+#pragma unroll
+                        for (int j = 0; j < kPwLoads; ++j)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(pw_rsrc, (__attribute__((address_space(3))) void *)pw_dump, 4, pvoff[j], kt * kTileBytes, 0, 0);
+                    }
+                };
+                for (unsigned kt = kt_begin + D; kt < kt_begin + kAhead; ++kt)
+                    prefetch(kt);
+                __builtin_amdgcn_s_barrier();
+                const unsigned nstages = (sp_end - sp_begin) * (KS / KT);
+                for (unsigned st = 0; st < nstages; ++st) {
+#pragma unroll
+                    for (int t = 0; t < KT; ++t)
+                        prefetch(kt_begin + st * KT + t + kAhead);
+                    if (st + 1 < nstages)
+                        __builtin_amdgcn_s_barrier();
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                return;
+            }
         }
     } else {
         dma_stage(kt_begin, 0);
