@@ -584,6 +584,13 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                     for (int q = 0; q < 2; ++q)
                         wop[np][q] = i32x8{(int)pw[q][0], (int)pw[q][1], (int)pw[q][2], (int)pw[q][3], 0, 0, 0, 0};
                 }
+                if constexpr (kRefill && !(PETIT_ABLATE_N32 & 2)) {
+                    // the merged operands are copies: the ring slot is free as soon as they exist, and its refill goes out BEFORE the tile's MFMAs
+                    // (requests spread over the stage instead of a burst behind the barrier: -2...6 % at M = 512, profiles/r03_native_ablation.md)
+#pragma unroll
+                    for (int nt = 0; nt < 2 * NP; ++nt)
+                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
+                }
                 static_for<0, 2>([&](auto q_c) {
                     constexpr int q = decltype(q_c)::value, gi = 2 * TI + q; // group index inside the stage
                     // fragments of the next group (next operand, or the next tile of the stage) while this group's MFMAs run
@@ -617,11 +624,6 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                if constexpr (kRefill && PF == 1 && !(PETIT_ABLATE_N32 & 2)) {
-#pragma unroll
-                    for (int nt = 0; nt < 2 * NP; ++nt)
-                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
-                }
                 (void)a_cur, (void)sc_cur, (void)refills;
             });
             if constexpr (PF == 1) {
@@ -638,8 +640,9 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 if constexpr (kNextStage) {
                     constexpr int kPrevRefills = [] {
                         int n = 0;
-                        for (int j = 1; j < PF; ++j)
+                        for (int j = 1; j < PF; ++j) // (the refills of the PF - 1 stages before this one)
                             n += n32_stage_refills(kLast, T0 - j * KT, KT, D, KS, NP);
+                        n += n32_stage_refills(kLast, T0, KT, D, KS, NP); // (this stage's refills are already in the queue)
                         return (PETIT_ABLATE_N32 & 2) ? 0 : n;
                     }();
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -649,14 +652,6 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 #endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<0, KT>([&](auto t_c) {
-                    constexpr int T = T0 + decltype(t_c)::value, SLOT = T % D;
-                    if constexpr ((!kLast || (T + D < KS)) && !(PETIT_ABLATE_N32 & 2)) {
-#pragma unroll
-                        for (int nt = 0; nt < 2 * NP; ++nt)
-                            wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
-                    }
-                });
                 cur_buf = cur_buf == (unsigned)(NBUF - 1) ? 0u : cur_buf + 1;
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -3,6 +3,7 @@
 # shipped ones; run `python petit-kernel_amd/build.py` first):
 #   <ahead>_<share>  PETIT_N32_PW=<ahead> PETIT_N32_PWSHARE=<share>: a PREFETCH wave touches the workgroup's weight lines <ahead> k-tiles early, every
 #                    <share>-th line per row block of the panel (share = 4: the four row blocks of a panel split the work)
+#   early            PETIT_N32_EARLY_REFILL=1: a tile's weight refills go out right after its MFMAs instead of after the stage barrier
 #   pf<N>            PETIT_N32_LWPF=<N>: the loader wave keeps N activation stages in flight (up to what vmcnt can count)
 # then on the GPU box: bash tools/ablate/run_pw.sh base 4_4 8_1 8_4 16_4 pf4 pf7
 R=$(cd "$(dirname "$0")/../.." && pwd)
@@ -17,6 +18,7 @@ build() { # name, defines
 for v in "${@:-4_4 8_1 8_4 16_4 pf4 pf7}"; do
   case $v in
     pf*) build $v "-DPETIT_N32_LWPF=${v#pf}" & ;;
+    early*) build $v "-DPETIT_N32_EARLY_REFILL=${v#early}" & ;;
     *)   build $v "-DPETIT_N32_PW=${v%_*} -DPETIT_N32_PWSHARE=${v#*_}" & ;;
   esac
 done

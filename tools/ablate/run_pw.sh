@@ -9,7 +9,7 @@ for v in ${@:-base 4_4 8_1 8_4 16_4}; do
 import csv
 best = {}
 for r in csv.DictReader(open('gpurun_out/pw/$v.csv')):
-    if '+loader' not in r['desc']: continue
+    if '+loader' not in r['desc'] and '$ALL' != '1': continue
     if r['checked'] != 'ok': print("NOT OK", r['solution'], r['checked'])
     key = (r['shape'], 'fp8' if 'mxfp8' in r['desc'] else 'fp4')
     us = float(r['us_median'])
