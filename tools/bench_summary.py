@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""tools/bench_summary.py <bench.json> [<bench_steps20.json>] -- the cell tables of profiles/rNN_summary.md from a bench.py line (stdout: markdown)."""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+d20 = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]) if len(sys.argv) > 2 else None
+cells = {(c["shape"], c["M"], c["dt"]): c for c in d["cells"]}
+shapes = ["qkv", "o", "gate_up", "down"]
+print(f"Headline (BASELINE configs[1], M = 1, N = K = 8192, bf16 x NVFP4, solution_id = -1): **{d['ms_per_step'] * 1e3:.2f} us/step = {d['value']:.0f} GB/s = "
+      f"{d['roofline']['frac']:.3f} of 8 TB/s** ({d['steps']} graph-replayed steps x {d['config'].get('timed_regions', 1)} regions, median)"
+      + (f"; as the driver runs it ({d20['steps']} steps): {d20['ms_per_step'] * 1e3:.2f} us = {d20['roofline']['frac']:.3f}." if d20 else "."))
+print("\nHBM-bound cells (us per call, fraction of 8 TB/s):\n")
+cols = [("bf16xnv", 1), ("bf16xnv", 4), ("bf16xnv", 8), ("bf16xnv", 16), ("fp16xnv", 16), ("fp16xmx", 1), ("fp16xmx", 16)]
+print("| shape | " + " | ".join(f"{dt} M={m}" for dt, m in cols) + " |")
+print("|---|" + "---|" * len(cols))
+for s in shapes:
+    print(f"| {s} | " + " | ".join(f"{cells[(s, m, dt)]['us']:.2f} us, {cells[(s, m, dt)]['frac']:.2f}" if (s, m, dt) in cells else "-" for dt, m in cols) + " |")
+print("\nM = 512 (TFLOP/s; fraction of 2.5 PF bf16 peak, native: of the 5 / 10 PF FP8 / FP4 peaks; native cells include the activation-quantiser launch):\n")
+cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"),
+        ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xdense hipblaslt", "hipBLASLt bf16 dense")]
+print("| shape | " + " | ".join(name for _, name in cols) + " |")
+print("|---|" + "---|" * len(cols))
+for s in shapes:
+    print(f"| {s} | " + " | ".join(f"{cells[(s, 512, dt)]['us']:.1f} us, {cells[(s, 512, dt)]['TF']:.0f} TF, {cells[(s, 512, dt)]['frac']:.2f}" if (s, 512, dt) in cells else "-"
+                                   for dt, _ in cols) + " |")
+print("\nLaunch-gap-bound shapes and the MLP block:\n\n| cell | us | rate |\n|---|---|---|")
+for (s, m, dt), c in cells.items():
+    if s.startswith("tp8"):
+        print(f"| three 1280 x 8192 shards, M = {m}, {dt.split()[-1]} | {c['us']:.2f} | {c['GBs']} GB/s |")
+    elif s == "mlp":
+        print(f"| Llama-70B MLP block M = 512, {dt.split()[-1].replace('mlp_', '')} | {c['us']:.1f} | {c['TF']:.0f} TFLOP/s |")

@@ -13,10 +13,10 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 cd $R; cat gpurun_out/bench_${TAG}.json; head -3 gpurun_out/prof_${TAG}/bench_kernel_stats.csv | cut -c1-300
 # MFMA utilisation at M = 512 (BASELINE config 5): the default (tiled dequant) kernel and the native-FP4 kernel on gate_up
 cd /tmp
-# (native: the FP4 x FP4 32x32x64 kernel the sweeps rank first on gate_up: 128x256, two workgroups per CU, one k-tile per stage)
+# (native: the FP4 x FP4 32x32x64 kernel the class table picks on gate_up: 128x256, two workgroups per CU, two k-tiles per stage, two stages ahead)
 for v in "nv tiled" "mx native"; do
   set -- $v
-  EXTRA=""; [ "$2" = "native" ] && EXTRA="--native --solution 124d541623301004"
+  EXTRA=""; [ "$2" = "native" ] && EXTRA="--native --solution 124da41623301004"
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$2_${TAG} -o p -- python3 $R/tools/profile_one.py --m 512 --n 57344 --k 8192 --fmt $1 $EXTRA --iters 20 > $R/gpurun_out/pmc_mfma_$2_${TAG}.log 2>&1
 done
 cd $R
