@@ -239,7 +239,19 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     const bool mid = m > 4; // 5..16
     // workgroup width: the widest of 16 / 32 / 64 columns that still leaves >= ~0.6 workgroups per CU (every swept winner at M = 5..16:
     // N = 4096 -> 16, 6144..8192 -> 32, 10240..28672 -> 64 columns; a wider tile shares the activation block among more columns)
-    const int want_nt = m <= 2 ? 1 : (mid && 5u * ntiles >= 12u * arch.num_cus) ? 4 : 4u * ntiles >= 5u * arch.num_cus ? 2 : 1;
+    int want_nt = m <= 2 ? 1 : 4u * ntiles >= 5u * arch.num_cus ? 2 : 1;
+    if (mid) {
+        // ... refined in round 3: the width whose grid fills the most of the chip's workgroup slots, rounds counted whole, wider on a tie.  Reproduces
+        // every pick of the rule above on the swept shapes and adds 48 columns for N = 10240 (214 workgroups instead of 160: qkv M = 16 13.8 -> 12.1 us)
+        // and 112 / 224 for N = 28672 / 57344 (256 workgroups).
+        double best_fill = 0.0;
+        for (const int nt : {1, 2, 3, 4, 7}) {
+            const unsigned wgs = (ntiles + nt - 1) / nt, rounds = (wgs + arch.num_cus - 1) / arch.num_cus;
+            const double f = (double)wgs / ((double)rounds * arch.num_cus);
+            if (f >= best_fill - 1e-9)
+                best_fill = f > best_fill ? f : best_fill, want_nt = nt;
+        }
+    }
     const double target_waves = (double)arch.num_cus * (mid ? 4 : m > 2 ? 8 : 16);
     const SolutionEntry *best = nullptr;
     double best_score = -1e30;
