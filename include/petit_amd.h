@@ -50,8 +50,17 @@ typedef enum petit_data_type {
     PETIT_DTYPE_FP16 = 4,
     PETIT_DTYPE_BF16 = 5,
     PETIT_DTYPE_FP8_E5M2_FNUZ = 6,
-    PETIT_DTYPE_MXFP4_E2M1 = 7 /* MXFP4: e8m0 scales, group 32 */
+    PETIT_DTYPE_MXFP4_E2M1 = 7, /* MXFP4: e8m0 scales, group 32 */
+    /* Extension (not in the reference's enum), as hints->b_type on the MXFP4 entry points: MXFP4 weights whose EVERY e8m0 block scale byte
+     * lies in 114..140 (2^-13 .. 2^13), so that e2m1 x scale is a normal fp16 number -- true of real checkpoints, whose block scales sit within a few
+     * binades of 1.  The caller's promise: nothing checks it, and a scale outside the range over- or underflows in fp16.  With fp16 activations the
+     * library then converts the weights straight to fp16 (one MFMA per fragment, every kernel family: 20-25 % faster at M <= 16, ~2x at M = 512)
+     * instead of the exact bf16 hi / lo split it needs for arbitrary e8m0 scales; with bf16 activations, the native sentinels or a native id it is
+     * the same as PETIT_DTYPE_MXFP4_E2M1.  Kernel ids carry their own element nibble: enumerate them with this type in the hints. */
+    PETIT_DTYPE_MXFP4_E2M1_F16RANGE = 8
 } petit_data_type;
+#define PETIT_MXFP4_F16RANGE_SCALE_MIN 114
+#define PETIT_MXFP4_F16RANGE_SCALE_MAX 140
 
 /* PetitSolutionHints, quantization/gemm.h:112-117.  Ignored when an explicit
  * solution id is passed.  require_high_precision is accepted for
@@ -59,7 +68,7 @@ typedef enum petit_data_type {
  * changes the result. */
 typedef struct petit_solution_hints {
     int32_t a_type; /* PETIT_DTYPE_FP16 or PETIT_DTYPE_BF16 */
-    int32_t b_type; /* PETIT_DTYPE_FP4_E2M1 or PETIT_DTYPE_MXFP4_E2M1 */
+    int32_t b_type; /* PETIT_DTYPE_FP4_E2M1, PETIT_DTYPE_MXFP4_E2M1 or PETIT_DTYPE_MXFP4_E2M1_F16RANGE */
     int32_t c_type; /* must equal a_type */
     int32_t require_high_precision;
 } petit_solution_hints;
@@ -344,7 +353,7 @@ int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned coun
  * enumerates and times every solution on the user's device but leaves the winning id for the user to carry around).
  *
  * petit_gemm_tune() runs every kernel of the class that fits (m, n, k) and `workspace_bytes`, with the K splits its kind
- * supports: first CHECKS the candidate's output against the class's reference kernel (|c - ref| <= tolerance * max(1, |ref|),
+ * supports: first CHECKS the candidate's output against the class's reference kernel (|c - ref| <= tolerance * max(rms(ref), |ref|),
  * every element), then times it with HIP events on `stream` (launches rotate over the weight copies so that the 256 MB
  * Infinity Cache cannot serve them), and returns the fastest id and its microseconds per launch.  With persist != 0 the
  * winner becomes what PETIT_SOLUTION_AUTO (klass 0) or PETIT_SOLUTION_AUTO_NATIVE_* (klass 8 / 4) picks for (dtypes, n, k)

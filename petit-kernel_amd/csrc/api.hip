@@ -33,9 +33,14 @@ struct Family {
 };
 
 bool family_for(int a_type, int b_type, Family *out) {
-    const bool mx = (b_type == kDataTypeMxFp4e2m1);
+    const bool mx = is_mx_type(b_type);
     if (b_type != kDataTypeFp4e2m1 && !mx)
         return false;
+    if (a_type == kDataTypeFp16 && b_type == kDataTypeMxFp4e2m1F16Range) { // the caller's promise: every block scale in 114..140
+        out->entries = solutions_mx_f16r(&out->count);
+        out->elem_b = kElemBMxFp4F16Range, out->mfma = kMfmaFp16;
+        return true;
+    }
     if (a_type == kDataTypeBf16 && !mx) {
         out->entries = solutions_nv_bf16(&out->count);
         out->elem_b = kElemBNvFp4, out->mfma = kMfmaBf16;
@@ -437,11 +442,31 @@ const SolutionEntry *find_explicit(const Family &fam, uint64_t id) {
     const SolutionEntry *e = find_entry(fam, id);
     const unsigned am = (unsigned)(id >> 48) & 0xf;
     // NVFP4-only kernel kinds named on the MXFP4 entry point: the plain staged kernel with the same geometry
-    if (!e && fam.elem_b == kElemBMxFp4 && am >= 5 && am <= 7)
+    if (!e && fam.elem_b != kElemBNvFp4 && am >= 5 && am <= 7)
         e = find_entry(fam, (id & ~((uint64_t)0xf << 48)) | ((uint64_t)(am - 4) << 48));
-    if (!e && fam.elem_b == kElemBMxFp4 && (am == 4 || am == 14 || am == 15))
+    if (!e && fam.elem_b != kElemBNvFp4 && (am == 4 || am == 14 || am == 15))
         e = find_entry(fam, (id & ~((uint64_t)0xf << 48)) | ((uint64_t)(am == 4 ? 1 : am == 14 ? 2 : 3) << 48));
     return e;
+}
+
+// The weight type a call runs with.  PETIT_DTYPE_MXFP4_E2M1_F16RANGE in hints->b_type (the caller's promise that every e8m0 block scale lies in
+// 114..140) selects the single-MFMA fp16 family -- for fp16 activations and the exact class only; bf16 activations, the native sentinels and explicit
+// native ids run as plain MXFP4 (those kernels are indifferent to the promise).
+int effective_b_type(const petit_solution_hints *hints, int entry_b_type, uint64_t solution_id) {
+    if (!hints || !is_mx_type(entry_b_type))
+        return entry_b_type;
+    if (hints->b_type != kDataTypeMxFp4e2m1F16Range || hints->a_type != kDataTypeFp16)
+        return kDataTypeMxFp4e2m1;
+    const unsigned kind = (unsigned)(solution_id >> 48) & 0xf;
+    if (auto_class(solution_id) != kClassExact || (!is_auto_id(solution_id) && (kind == 9 || kind == 13)))
+        return kDataTypeMxFp4e2m1;
+    return kDataTypeMxFp4e2m1F16Range;
+}
+// (for the entry points that take the type from the hints alone)
+petit_solution_hints effective_hints(const petit_solution_hints *hints, uint64_t solution_id) {
+    petit_solution_hints h = *hints;
+    h.b_type = effective_b_type(hints, hints->b_type, solution_id);
+    return h;
 }
 
 } // namespace
@@ -454,7 +479,7 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
                     int cap) {
     Family fam;
     if (!family_for(a_type, b_type, &fam) || !shape_ok(n, k) || m == 0 || (klass != kClassExact && b_type != kDataTypeMxFp4e2m1))
-        return 0;
+        return 0; // (the native class: plain MXFP4 -- the range-limited family has no native kernels and needs none)
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
     int count = 0;
     auto push = [&](const SolutionEntry &e, unsigned sk, bool front) {
@@ -638,21 +663,21 @@ int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b
                                const float *global_scale, unsigned m, unsigned n, unsigned k,
                                const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
     // the reference forces element_b = MxFp4 into the id (gemm_fp4_fp16_grid.cc:79-95): find_explicit does the same
-    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, nullptr, 0, stream);
+    return gemm_impl(effective_b_type(hints, kDataTypeMxFp4e2m1, solution_id), c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, nullptr, 0, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                   const float *global_scale, unsigned m, unsigned n, unsigned k,
                                   const petit_solution_hints *hints, uint64_t solution_id,
                                   const petit_epilogue *epilogue, void *stream) {
-    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, nullptr, 0, stream);
+    return gemm_impl(effective_b_type(hints, kDataTypeMxFp4e2m1, solution_id), c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, nullptr, 0, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                   const float *global_scale, unsigned m, unsigned n, unsigned k,
                                   const petit_solution_hints *hints, uint64_t solution_id,
                                   const petit_epilogue *epilogue, void *workspace, uint64_t workspace_bytes, void *stream) {
-    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, workspace,
+    return gemm_impl(effective_b_type(hints, kDataTypeMxFp4e2m1, solution_id), c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, workspace,
                      workspace_bytes, stream);
 }
 
@@ -668,8 +693,11 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
     Family fam;
     bool ok;
     const bool act = epilogue_act(epilogue, &ok);
-    if (!ok || !hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) ||
-        m == 0)
+    if (!ok || !hints)
+        return 0;
+    const petit_solution_hints eff = effective_hints(hints, solution_id);
+    hints = &eff;
+    if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
         return 0;
     if (is_auto_id(solution_id)) {
         const int klass = auto_class(solution_id);
@@ -791,7 +819,7 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
                              uint64_t *sols, unsigned *n_sols) {
     if (!hints || !n_sols)
         return -1;
-    if (hints->b_type != kDataTypeFp4e2m1 && hints->b_type != kDataTypeMxFp4e2m1)
+    if (hints->b_type != kDataTypeFp4e2m1 && !is_mx_type(hints->b_type))
         return -1; // algo_chooser.cc:20-23
     Family fam;
     unsigned count = 0;
@@ -816,8 +844,11 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
     Family fam;
     bool ok;
     const bool act = epilogue_act(epilogue, &ok);
-    if (!ok || !hints || hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) ||
-        !shape_ok(n, k) || m == 0)
+    if (!ok || !hints)
+        return 0;
+    const petit_solution_hints eff = effective_hints(hints, solution_id);
+    hints = &eff;
+    if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
         return 0;
     if (!is_auto_id(solution_id)) {
         const SolutionEntry *e = find_explicit(fam, solution_id);
@@ -946,7 +977,7 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kErrBadArgument;
     const unsigned elem_b = (unsigned)(id >> 28) & 0xf, mfma = (unsigned)(id >> 32) & 0xf;
     const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8 || mfma == kMfmaFp4) ? kDataTypeBf16 : kDataTypeFp16;
-    const int b_type = elem_b == kElemBMxFp4 ? kDataTypeMxFp4e2m1 : kDataTypeFp4e2m1;
+    const int b_type = elem_b == kElemBMxFp4 ? kDataTypeMxFp4e2m1 : elem_b == kElemBMxFp4F16Range ? kDataTypeMxFp4e2m1F16Range : kDataTypeFp4e2m1;
     Family fam;
     const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_entry(fam, id) : nullptr;
     if (!e) {
@@ -969,18 +1000,18 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     }
     if (s.am == kWideAm) {
         snprintf(buf, len, "wide32 %sx%s ks%d mb%d np%d waves%d kgroups%d d%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x16 mfma)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : b_type == kDataTypeMxFp4e2m1F16Range ? "mxfp4(f16-range scales)" : "nvfp4", s.ks,
                  s.mt, s.nt / 2, s.wn, s.wm == 3 ? 2 : 1, s.d, s.pa, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * (s.wm == 3 ? 2 : 1));
         return kOk;
     }
     if (s.am == kTiledAm) {
         snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d splitk%u  (wg tile %dx%d, %d threads)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : b_type == kDataTypeMxFp4e2m1F16Range ? "mxfp4(f16-range scales)" : "nvfp4", s.ks,
                  s.mt, s.nt, s.wn, s.d, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
         return kOk;
     }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",
-             a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
+             a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : b_type == kDataTypeMxFp4e2m1F16Range ? "mxfp4(f16-range scales)" : "nvfp4", s.ks,
              s.mt, s.nt, s.wn, s.wk, s.d, am_rows(s.am), solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
              64 * s.wn * s.wk);
     if (s.wm == 2 && s.am < kDecodeAm) // (the 8-row decode kernel also carries warp_partition_m = 2: solution.h)

@@ -131,6 +131,15 @@ __device__ __forceinline__ bf16x8 unpack_mx(Bf16, unsigned w, float s) {
 }
 
 __device__ __forceinline__ bf16x8 unpack_mx(Fp16Split, unsigned w, float s) { return unpack_mx(Bf16{}, w, s); }
+// MXFP4 -> fp16 with the block scale in the convert: exact iff every product e2m1 x 2^(s - 127) is a NORMAL fp16 number, i.e. 114 <= s <= 140
+// (0.5 x 2^-13 = 2^-14 ... 6 x 2^13 = 49152).  Only the range-limited family (gemm_mx_f16r.hip: the caller promises that range) is built on it.
+__device__ __forceinline__ f16x8 unpack_mx(Fp16, unsigned w, float s) {
+    f16x2 q0 = cvt_fp4_f16<0>(w, s);
+    f16x2 q1 = cvt_fp4_f16<1>(w, s);
+    f16x2 q2 = cvt_fp4_f16<2>(w, s);
+    f16x2 q3 = cvt_fp4_f16<3>(w, s);
+    return f16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
+}
 
 // 8 fp16 values -> (hi, lo) bf16 fragments with hi + lo == the fp16 value exactly.
 __device__ __forceinline__ void split_f16(const u32x4 &h, u32x4 &hi, u32x4 &lo) {

@@ -50,7 +50,7 @@
 namespace petit_amd {
 
 enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
-enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u };
+enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u, kElemBMxFp4F16Range = 3u };
 enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u, kMfmaFp4 = 6u, kMfmaFp4ActFp16 = 6u | 8u };
 
 struct StreamShape {
@@ -119,6 +119,7 @@ const SolutionEntry *solutions_nv_bf16(int *count);
 const SolutionEntry *solutions_nv_f16(int *count);
 const SolutionEntry *solutions_mx_bf16(int *count);
 const SolutionEntry *solutions_mx_f16(int *count);
+const SolutionEntry *solutions_mx_f16r(int *count); // fp16 x MXFP4 with block scales in the fp16-safe range (gemm_mx_f16r.hip)
 // the activation quantiser of the 32x32x64 native kernels, stand-alone (gemm_mx_{bf16,f16}.hip): format 8 = MXFP8, 4 = MXFP4
 int quantize32_bf16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);
 int quantize32_f16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);

@@ -16,6 +16,7 @@ from . import compiled, offline, ops, tuning
 from .ops import QuantizedActivations, mul_fp4_a16_grouped, mul_mxfp4_native, quantize_activations
 from .tuning import tune, tune_tensors
 from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
+from ._lib import MXFP4_F16RANGE_SCALE_MAX, MXFP4_F16RANGE_SCALE_MIN
 
 # operator layer: the compiled torch.library binding when it is built and loads (csrc/torch_binding.cpp), else the
 # ctypes layer; both are thin shims over the same C ABI (there is no other compute path)
@@ -33,6 +34,11 @@ class DataType(enum.Enum):
     mxfloat4_e2m1 = 6
 
 
+# Extension, as PetitSolutionHints.b_type (a raw value of the C++ numbering; the reference's Python enum above stays as it is): MXFP4 whose every
+# e8m0 scale byte lies in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h) -- enumerates / resolves the fp16 single-MFMA family.
+DTYPE_MXFP4_E2M1_F16RANGE = 8
+
+
 def repack_nvfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
     return _impl.repack_nvfp4(qw, size_n, size_k)
 
@@ -47,7 +53,17 @@ def repack_mxfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
 
 
 def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
-    return _impl.process_mxfp4_scales(scales, size_n, size_k)
+    out = _impl.process_mxfp4_scales(scales, size_n, size_k)
+    # One look at the raw scales, at load time: do all e8m0 bytes lie in 114..140 (e2m1 x scale a normal fp16 number)?  Real checkpoints do.
+    # mul_mxfp4_a16 reads the mark off THIS tensor object and then gives fp16 activations the single-MFMA family
+    # (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h); a tensor without the mark (re-wrapped, copied, traced) takes the exact split path.
+    try:
+        if not torch.compiler.is_compiling() and scales.is_cuda and scales.numel():
+            lo, hi = torch.aminmax(scales)
+            out.petit_scales_in_fp16_range = bool(int(lo) >= MXFP4_F16RANGE_SCALE_MIN and int(hi) <= MXFP4_F16RANGE_SCALE_MAX)
+    except Exception:  # noqa: BLE001  (fake tensors, exotic subclasses: no mark, the exact path)
+        pass
+    return out
 
 
 def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
@@ -61,7 +77,14 @@ def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scal
 
 def mul_mxfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
                   size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None,
-                  activation: str = None) -> torch.Tensor:
+                  activation: str = None, scales_in_fp16_range: bool = None) -> torch.Tensor:
+    # scales_in_fp16_range (extension, fp16 activations only): every e8m0 scale byte in 114..140 -- None = the mark
+    # process_mxfp4_scales left on `s` (False when there is none); True is the caller's promise, False forces the exact split path.
+    if scales_in_fp16_range is None:   # (explicit kernel ids keep the plain MXFP4 meaning they were enumerated with)
+        scales_in_fp16_range = solution_id == -1 and getattr(s, "petit_scales_in_fp16_range", False)
+    fast = bool(scales_in_fp16_range) and a.dtype == torch.float16
+    if fast:
+        return _impl.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation, True)
     return _impl.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 

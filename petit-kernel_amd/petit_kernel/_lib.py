@@ -26,6 +26,8 @@ CXX_DTYPE_FP4_E2M1 = 3
 CXX_DTYPE_FP16 = 4
 CXX_DTYPE_BF16 = 5
 CXX_DTYPE_MXFP4_E2M1 = 7
+CXX_DTYPE_MXFP4_E2M1_F16RANGE = 8   # extension: MXFP4 with every e8m0 scale in 114..140 (include/petit_amd.h)
+MXFP4_F16RANGE_SCALE_MIN, MXFP4_F16RANGE_SCALE_MAX = 114, 140
 PETIT_DTYPE_FP32 = 100   # petit_dequant_packed_weights only
 
 

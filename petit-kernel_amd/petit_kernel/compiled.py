@@ -81,5 +81,6 @@ def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bi
     return torch.ops.petit_kernel.mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None):
-    return torch.ops.petit_kernel.mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None, f16_range=False):
+    op = torch.ops.petit_kernel.mul_mxfp4_a16_f16range if f16_range else torch.ops.petit_kernel.mul_mxfp4_a16
+    return op(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))

@@ -193,7 +193,7 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
         _check(size_n % 32 == 0, f"silu_mul needs size_n % 32 == 0 (gate / up halves of whole tiles), got {size_n}")
     c = torch.empty((size_m, size_n // 2 if act else size_n), dtype=A.dtype, device=A.device)
     a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
-    b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
+    b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE if kind == "mxr" else _lib.CXX_DTYPE_MXFP4_E2M1
     # require_high_precision: the reference turns it on for arch <= gfx90a when
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
@@ -235,14 +235,15 @@ def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bi
     return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
-    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue."""
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None, f16_range=False) -> torch.Tensor:
+    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue.
+    f16_range: the caller's promise that every e8m0 scale byte lies in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE)."""
     _check(B.size(0) == size_n // _LAYOUT_N, f"B.size(0) = {B.size(0)} is not size_n / 16 = {size_n // _LAYOUT_N}")
     _check(B.size(1) == size_k * _LAYOUT_N // _PACK,
            f"B.size(1) = {B.size(1)} is not packed size = {size_k * _LAYOUT_N // _PACK}")
     _check(s.size(0) == size_n // 32, f"s.size(0) = {s.size(0)} is not size_n / 32 = {size_n // 32}")
     _check(s.size(1) == size_k, f"s.size(1) = {s.size(1)} is not size_k = {size_k}")
-    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
+    return _mul("mxr" if f16_range else "mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def get_fp4_solutions(*args) -> list:

@@ -69,7 +69,9 @@ def check_gemm(c_bits, ref_f32, is_bf16, sum_abs=None, sum_abs_coef=1e-5):
     assert np.median(rel) < (2 ** -8 if is_bf16 else 2 ** -11)
 
 
-def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1):
+def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1, mx_f16_range=None):
+    """mx_f16_range (MXFP4 only): None = what a caller gets (process_mxfp4_scales marks scales that lie in 114..140 and fp16 activations then take
+    the single-MFMA family under solution_id = -1), False = force the exact hi / lo split family, True = the caller's promise."""
     dtype = torch.bfloat16 if is_bf16 else torch.float16
     a = from_bits(a_bits, dtype).to(DEV)
     qd = torch.from_numpy(q).to(DEV)
@@ -81,7 +83,7 @@ def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1):
     else:
         b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
         sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
-        c = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, solution_id)
+        c = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, solution_id, scales_in_fp16_range=mx_f16_range)
     torch.cuda.synchronize()
     assert c.shape == (m, n) and c.dtype == dtype and c.is_cuda
     return bits(c)
@@ -275,6 +277,54 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     a, q, s, gs = random_problem(kind, m, n, k, 1000 + m + n + k, is_bf16)
     c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k)
     check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+    if kind == "mx" and not is_bf16:   # the call above took the fp16-range family (scales 119..135 are marked); the exact split family too
+        c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, mx_f16_range=False)
+        check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+
+
+MX_F16RANGE_PROBLEMS = [(1, 256, 2048), (3, 96, 512), (8, 160, 1024), (16, 288, 1024), (40, 64, 3072), (64, 128, 2048), (130, 256, 1024), (300, 512, 768),
+                        (2, 4128, 4096), (512, 1024, 2048)]
+
+
+@pytest.mark.parametrize("m,n,k", MX_F16RANGE_PROBLEMS)
+def test_fp16_mxfp4_f16range_every_solution(pk, m, n, k):
+    """fp16 x MXFP4 with every e8m0 scale in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE): weights convert straight to fp16, one MFMA per
+    fragment, every kernel family.  Scales drawn over the WHOLE promised range, both ends included; every enumerated kernel and the default
+    pick against the oracle, and the default pick against the exact split family on the same inputs."""
+    a, q, s, gs = random_problem("mx", m, n, k, 4242 + m + n + k, False, mx_band=(114, 141))
+    s[0, 0], s[-1, -1] = 114, 140
+    ref = oracle_ref("mx", a, False, q, s, gs)
+    sum_abs = oracle_sum_abs("mx", a, False, q, s, gs)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.float16
+    h.b_type = pk.DTYPE_MXFP4_E2M1_F16RANGE
+    sols = pk.ops.get_fp4_solutions(h, m, n, k)
+    plain = pk.PetitSolutionHints()
+    plain.a_type = plain.c_type = torch.float16
+    plain.b_type = pk.DataType.mxfloat4_e2m1
+    assert sols and not set(sols) & set(pk.ops.get_fp4_solutions(plain, m, n, k))   # ids carry their own element nibble
+    for sid in [-1] + list(sols):
+        check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k, sid, mx_f16_range=True), ref, False, sum_abs)
+    # what an unchanged call site gets: the mark -> the same family under solution_id = -1 (bit-identical to the explicit promise)
+    auto = run_case(pk, "mx", a, False, q, s, gs, m, n, k)
+    assert np.array_equal(auto, run_case(pk, "mx", a, False, q, s, gs, m, n, k, mx_f16_range=True))
+    assert (pk.ops.resolve_solution(h, m, n, k) & ~(0xF << 60)) | (1 << 60) in sols   # (the pick may carry a K split)
+
+
+def test_fp16_mxfp4_f16range_mark(pk):
+    """process_mxfp4_scales marks in-range scales and only those; out-of-range scales keep the exact split family (and stay correct)."""
+    m, n, k = 5, 128, 1024
+    for band, expect in (((114, 141), True), ((113, 141), False), ((114, 142), False), ((0, 255), False)):
+        a, q, s, gs = random_problem("mx", m, n, k, 99, False, mx_band=band)
+        s[0, 0], s[-1, -1] = band[0], band[1] - 1
+        sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+        assert getattr(sp, "petit_scales_in_fp16_range", None) is expect
+        if band != (0, 255):   # (the full range overflows fp16 outputs: covered by test_mx_extreme_scales-style cases below)
+            check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k), oracle_ref("mx", a, False, q, s, gs), False,
+                       oracle_sum_abs("mx", a, False, q, s, gs))
+    # bf16 activations ignore the mark and the promise
+    a, q, s, gs = random_problem("mx", m, n, k, 100, True, mx_band=(114, 141))
+    assert np.array_equal(run_case(pk, "mx", a, True, q, s, gs, m, n, k), run_case(pk, "mx", a, True, q, s, gs, m, n, k, mx_f16_range=True))
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256), (7, 96, 2048),
@@ -942,7 +992,10 @@ class FullSizeProblem:
         else:
             self.b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
             self.sp = pk.process_mxfp4_scales(torch.from_numpy(self.s).to(DEV), n, k)
-            self.mul = pk.mul_mxfp4_a16
+            # mx_f16_range: None = what a caller gets (the scales, 119..135, are marked: fp16 activations take the single-MFMA family under -1),
+            # False = force the exact hi / lo split family
+            self.mx_f16_range = None
+            self.mul = lambda *args, **kw: pk.mul_mxfp4_a16(*args, scales_in_fp16_range=self.mx_f16_range, **kw)
         del qd
         self.gs = 0.75
         self.gsd = torch.tensor([self.gs], dtype=torch.float32, device=DEV)
@@ -1102,23 +1155,30 @@ def test_bench_cells_parity(pk):
     assert [c["mode"] for c in full_plan if c["shape"] == "mlp"] == ["mlp_" + m_ for m_ in BL.MlpBlock.MODES]   # -> test_bench_mlp_block_cells
     assert {c["mode"] for c in full_plan if c["shape"].startswith("tp8")} == {"separate", "grouped"}            # -> test_grouped_launch
     plan = [c for c in full_plan if c["mode"] != "hipblaslt" and c["shape"] in BL.LLAMA70B]
-    assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx")}
+    assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx"), ("fp16", "mxr")}
     assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512}          # configs[1..2] + M = 512
     ran = 0
     for shape in BL.SHAPE_ORDER:
         n, k = BL.LLAMA70B[shape]
         for w in ("nv", "mx"):
-            cells = [c for c in plan if c["shape"] == shape and c["w"] == w]
+            cells = [c for c in plan if c["shape"] == shape and c["w"] in ((w, "mxr") if w == "mx" else (w,))]
             if not cells:
                 continue
             P = FullSizeProblem(pk, w, n, k, 7 * n + k + len(w))
             for c in cells:
                 m, is_bf16, mode = c["M"], c["a"] == "bf16", c["mode"]
                 a = P.activations(m, is_bf16, 900 + m)
-                tag = f"{shape} M={m} {c['a']}x{w} {mode}"
+                tag = f"{shape} M={m} {c['a']}x{c['w']} {mode}"
+                if w == "mx":   # bench.py times "mx" with plain MXFP4 hints (fp16: the split family) and "mxr" with the fp16-range promise
+                    P.mx_f16_range = None if c["w"] == "mxr" else False
                 if mode == "auto":
-                    picked = pk.ops.resolve_solution(P.hints(is_bf16), m, n, k, -1)
+                    hints = P.hints(is_bf16)
+                    if c["w"] == "mxr":
+                        assert P.sp.petit_scales_in_fp16_range is True and not is_bf16
+                        hints.b_type = pk.DTYPE_MXFP4_E2M1_F16RANGE
+                    picked = pk.ops.resolve_solution(hints, m, n, k, -1)
                     assert picked and (picked >> 48) & 0xF not in (9, 13), tag
+                    assert ((picked >> 28) & 0xF == 3) == (c["w"] == "mxr"), tag
                     P.check_properties(m, is_bf16)
                     P.check_sampled(P.run(a, is_bf16), a, is_bf16, f"{tag} -> {picked:#x}")
                 else:
@@ -1524,6 +1584,20 @@ def test_in_library_tune_picks_checks_and_persists(pk, tmp_path):
             "print('%%x' %% _lib.lib.petit_gemm_default_solution(C.byref(h), %s, %s, %s))" % (ROOT / "petit-kernel_amd", at, bt, at, lo, n, k))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PETIT_AMD_TUNE_FILE=str(path)), capture_output=True, text=True, check=True)
     assert out.stdout.strip().splitlines()[-1] == sol
+
+
+def test_inlib_tune_ranks_large_m_kernels_on_wide_range_mx_outputs(pk):
+    """Regression (round 3): the tuner compared a candidate with its reference kernel as |c - ref| <= tol * max(1, |ref|).  On a long K with
+    MXFP4 block scales up to 2^8 the outputs have an rms of ~1e4 and elements where the terms cancel differ by ~1 between two exact kernels'
+    summation orders: every tiled / 32x32 kernel was rejected and a streaming kernel several times slower won.  The floor is the output's rms now."""
+    m, n, k = 256, 512, 14336
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    b = torch.randint(-2 ** 31, 2 ** 31 - 1, (n // 16, 2 * k), generator=gen, dtype=torch.int32, device=DEV)
+    sp = torch.randint(119, 136, (n // 32, k), generator=gen, dtype=torch.uint8, device=DEV)
+    a = torch.randn((m, k), generator=gen, device=DEV, dtype=torch.float32).to(torch.bfloat16)
+    gs = torch.ones(1, dtype=torch.float32, device=DEV)
+    sid, us = pk.tune_tensors(a, (b, sp), gs, m, n, k, kind="mxfp4", persist=False, rotate_mb=64)
+    assert (sid >> 48) & 0xF in (8, 12), pk.ops._lib.describe_solution(sid)   # a tiled (16x16x32) or 32x32x16 large-M kernel
 
 
 def test_autotune_on_first_sight(pk, tmp_path):
