@@ -123,6 +123,35 @@ def test_solution_enumeration_and_ids():
     assert auto in sols
 
 
+def test_mxfp4_f16range_family_enumerates_without_a_gpu():
+    """The fp16-range MXFP4 extension type (include/petit_amd.h): header value = Python value; with fp16 activations it names a family of its own
+    (element nibble 3, disjoint ids, describe says so), with bf16 activations it is plain MXFP4; NVFP4 entry points do not know it."""
+    import re
+    from petit_kernel import _lib
+    hdr = (ROOT / "include" / "petit_amd.h").read_text()
+    assert int(re.search(r"PETIT_DTYPE_MXFP4_E2M1_F16RANGE = (\d+)", hdr).group(1)) == _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE == 8
+    assert (int(re.search(r"PETIT_MXFP4_F16RANGE_SCALE_MIN (\d+)", hdr).group(1)), int(re.search(r"PETIT_MXFP4_F16RANGE_SCALE_MAX (\d+)", hdr).group(1))) == \
+        (_lib.MXFP4_F16RANGE_SCALE_MIN, _lib.MXFP4_F16RANGE_SCALE_MAX) == (114, 140)
+    # 0.5 * 2^(114 - 127) is the smallest normal fp16, 6 * 2^(140 - 127) the largest product below 65504
+    assert np.float16(0.5 * 2.0 ** (114 - 127)) == np.float16(2.0 ** -14) and 6 * 2.0 ** (140 - 127) < 65504 < 6 * 2.0 ** (141 - 127)
+
+    def ids(a, b, m=16, n=8192, k=8192):
+        h = _lib.SolutionHints(a, b, a, 0)
+        cnt = C.c_uint(0)
+        assert _lib.lib.petit_gemm_get_solutions(C.byref(h), m, n, k, None, C.byref(cnt)) == 0
+        buf = (C.c_uint64 * max(cnt.value, 1))()
+        assert _lib.lib.petit_gemm_get_solutions(C.byref(h), m, n, k, buf, C.byref(cnt)) == 0
+        return [int(buf[i]) for i in range(cnt.value)]
+    fast, split = ids(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE), ids(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1)
+    assert fast and all((i >> 28) & 0xF == 3 for i in fast) and all((i >> 28) & 0xF == 2 for i in split) and not set(fast) & set(split)
+    assert any((i >> 36) & 0xF == 2 and (i >> 48) & 0xF in (10, 11) for i in fast)   # the shared-tile kernel: not available to the split family
+    assert not any((i >> 36) & 0xF == 2 and (i >> 48) & 0xF in (10, 11) for i in split)
+    assert "f16-range" in _lib.describe_solution(fast[0]) and "f16-range" not in _lib.describe_solution(split[0])
+    assert ids(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE) == ids(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1)
+    dflt = _lib.lib.petit_gemm_default_solution(C.byref(_lib.SolutionHints(4, 8, 4, 0)), 16, 8192, 8192)
+    assert (dflt & ~(0xF << 60)) | (1 << 60) in fast
+
+
 def test_error_codes_without_a_gpu():
     """Paths that return before any launch: zero sizes, bad shapes, unknown ids."""
     from petit_kernel import _lib
