@@ -363,7 +363,7 @@ REFERENCE_GTEST_PROBLEMS = [
 ]
 
 
-@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
 def test_reference_gtest_problem_list(pk, kind, is_bf16):
     """Same bound as the reference's gtest (max(1e-2, 1 %), :36,53), on its whole problem list, every kernel."""
     h = pk.PetitSolutionHints()
