@@ -456,7 +456,13 @@ def mul_fp4_a16_grouped(kind: str, A: torch.Tensor, members, size_m: int, size_k
         outs.append(c)
         arr[i] = _lib.GroupMember(c.data_ptr(), B.data_ptr(), s.data_ptr(), gs.data_ptr(), bias.data_ptr() if bias is not None else None, n, 0)
     a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
-    hints = _CHints(a_type, _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1, a_type, 0)
+    b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1
+    # fp16 activations, default pick, EVERY member's scales marked by process_mxfp4_scales as lying in fp16's range: the single-MFMA family
+    # (PETIT_DTYPE_MXFP4_E2M1_F16RANGE), as mul_mxfp4_a16 does for one matrix
+    if kind == "mxfp4" and A.dtype == torch.float16 and int(solution_id) == -1 and \
+            all(getattr(mem[1], "petit_scales_in_fp16_range", False) for mem in members):
+        b_type = _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE
+    hints = _CHints(a_type, b_type, a_type, 0)
     with torch.cuda.device(A.device):
         err = _lib.lib.petit_gemm_fp4_fp16_grouped(arr, len(members), _ptr(A), size_m, size_k, C.byref(hints), C.c_uint64(_c_solution_id(solution_id)),
                                                    _stream(A))
