@@ -643,6 +643,12 @@ def test_compiled_and_ctypes_bindings_agree(pk):
             assert c1.shape == c2.shape and torch.equal(c1.view(torch.int16), c2.view(torch.int16)), (kind, sid, kw)
         check_gemm(bits(mul1(ad, b1, s1, gsd, m, n, k, -1)), oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16,
                    oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+        if kind == "mx" and not is_bf16:   # the fp16-range family (extension op / b_type) through both layers
+            for kw in ({}, {"bias": bias}, {"activation": "silu_mul"}):
+                c1, c2 = mul1(ad, b1, s1, gsd, m, n, k, -1, f16_range=True, **kw), mul2(ad, b1, s1, gsd, m, n, k, -1, f16_range=True, **kw)
+                assert c1.shape == c2.shape and torch.equal(c1.view(torch.int16), c2.view(torch.int16)), ("mx f16 range", kw)
+            check_gemm(bits(mul1(ad, b1, s1, gsd, m, n, k, -1, f16_range=True)), oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16,
+                       oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
 def test_compiled_ops_trace_without_graph_break(pk):
