@@ -322,6 +322,13 @@ def test_fp16_mxfp4_f16range_mark(pk):
         if band != (0, 255):   # (the full range overflows fp16 outputs: covered by test_mx_extreme_scales-style cases below)
             check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k), oracle_ref("mx", a, False, q, s, gs), False,
                        oracle_sum_abs("mx", a, False, q, s, gs))
+    # the in-library tuner ranks the family's own kernels
+    a, q, s, gs = random_problem("mx", m, n, k, 101, False, mx_band=(114, 141))
+    b = pk.repack_mxfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+    sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+    sid, us = pk.tune_tensors(from_bits(a, torch.float16).to(DEV), (b, sp), torch.tensor([gs], dtype=torch.float32, device=DEV), m, n, k,
+                              kind="mxfp4_f16range", persist=False, rotate_mb=16)
+    assert (sid >> 28) & 0xF == 3 and us > 0
     # bf16 activations ignore the mark and the promise
     a, q, s, gs = random_problem("mx", m, n, k, 100, True, mx_band=(114, 141))
     assert np.array_equal(run_case(pk, "mx", a, True, q, s, gs, m, n, k), run_case(pk, "mx", a, True, q, s, gs, m, n, k, mx_f16_range=True))
