@@ -24,6 +24,9 @@ print("|---|" + "---|" * len(cols))
 for s in shapes:
     print(f"| {s} | " + " | ".join(f"{cells[(s, 512, dt)]['us']:.1f} us, {cells[(s, 512, dt)]['TF']:.0f} TF, {cells[(s, 512, dt)]['frac']:.2f}" if (s, 512, dt) in cells else "-"
                                    for dt, _ in cols) + " |")
+if any(k[1] == 256 for k in cells):
+    print("\nfp16 x NVFP4 at M = 256 (the reference benchmark's middle column): " +
+          ", ".join(f"{s} {cells[(s, 256, 'fp16xnv')]['us']:.1f} us = {cells[(s, 256, 'fp16xnv')]['TF']:.0f} TFLOP/s" for s in shapes if (s, 256, "fp16xnv") in cells) + ".")
 print("\nLaunch-gap-bound shapes and the MLP block:\n\n| cell | us | rate |\n|---|---|---|")
 for (s, m, dt), c in cells.items():
     if s.startswith("tp8"):

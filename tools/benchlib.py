@@ -52,7 +52,9 @@ def bench_cell_plan() -> list:
         # detects and mul_mxfp4_a16 then uses by itself) -- the single-MFMA fp16 family
         plan += [dict(shape=shape, M=m, a="fp16", w="mxr", mode="auto") for m in (1, 16)]
     for shape in SHAPE_ORDER:
-        plan += [dict(shape=shape, M=512, a="bf16", w="nv", mode="auto"), dict(shape=shape, M=512, a="fp16", w="nv", mode="auto"),
+        # (M = 256 in the reference benchmark's default dtype: the middle column of its ENTRIES, tools/benchmarks/matmul.py:92-117)
+        plan += [dict(shape=shape, M=256, a="fp16", w="nv", mode="auto"),
+                 dict(shape=shape, M=512, a="bf16", w="nv", mode="auto"), dict(shape=shape, M=512, a="fp16", w="nv", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"), dict(shape=shape, M=512, a="fp16", w="mxr", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
                  dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt")]
