@@ -58,12 +58,21 @@ def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torc
     # mul_mxfp4_a16 reads the mark off THIS tensor object and then gives fp16 activations the single-MFMA family
     # (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h); a tensor without the mark (re-wrapped, copied, traced) takes the exact split path.
     try:
-        if not torch.compiler.is_compiling() and scales.is_cuda and scales.numel():
-            lo, hi = torch.aminmax(scales)
-            out.petit_scales_in_fp16_range = bool(int(lo) >= MXFP4_F16RANGE_SCALE_MIN and int(hi) <= MXFP4_F16RANGE_SCALE_MAX)
+        if not torch.compiler.is_compiling() and scales.is_cuda:
+            out.petit_scales_in_fp16_range = mxfp4_scales_in_fp16_range(scales)
     except Exception:  # noqa: BLE001  (fake tensors, exotic subclasses: no mark, the exact path)
         pass
     return out
+
+
+def mxfp4_scales_in_fp16_range(raw_scales: torch.Tensor) -> bool:
+    """True when every e8m0 byte of the RAW (unprocessed) MXFP4 scale tensor lies in 114..140 -- the condition under which fp16 activations may
+    take the single-MFMA family (PETIT_DTYPE_MXFP4_E2M1_F16RANGE).  For pipelines that process scales offline (petit_kernel.offline) and load the
+    packed tensors later: record this bit next to them and pass it as mul_mxfp4_a16(..., scales_in_fp16_range=bit)."""
+    if raw_scales.numel() == 0:
+        return False
+    lo, hi = torch.aminmax(raw_scales)
+    return bool(int(lo) >= MXFP4_F16RANGE_SCALE_MIN and int(hi) <= MXFP4_F16RANGE_SCALE_MAX)
 
 
 def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
@@ -100,6 +109,7 @@ __all__ = [
     "mul_nvfp4_a16",
     "mul_mxfp4_a16",
     "get_fp4_solutions",
+    "mxfp4_scales_in_fp16_range",
     "DataType",
     "PetitSolutionHints",
     "tune",
