@@ -100,12 +100,13 @@ def cpu_baseline(a, gs, q, s, budget_s: float = 10.0):
     }
 
 
-def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
+def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False) -> dict:
     """The whole metric, cell list shared with the parity test (tools/benchlib.py bench_cell_plan): M in {1, 4, 8, 16, 512} x
     the four Llama-3-70B linears for bf16 x NVFP4, fp16 x NVFP4 (the reference benchmark's default dtype) at M = 16 / 512,
     fp16 x MXFP4 at M = 1 / 16, bf16 x MXFP4 at M = 512, the native-FP4 class through ITS default pick (solution_id -2 / -3:
     what an opted-in caller gets, quantiser launch included) and hipBLASLt bf16 on a dense weight.
-    Cells are compact (the driver keeps only the tail of stdout): id in hex, description on stderr."""
+    Every finished cell goes to the parent as one JSON object (with us_min, the kernel id and its description: the parent writes
+    those to the side file gpurun_out/bench_cells_full.json); the parent prints compact rows (main())."""
     import benchlib as BL
     from petit_kernel import _lib
     t0 = time.time()
@@ -139,7 +140,8 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                     weights.clear()
                     torch.cuda.empty_cache()
                     weights[key] = BL.GroupedGemm(w, 3, 1280, 8192, m, dtype, dev)
-                print(f"[bench] cell {shape} M={m} {mode}", file=sys.stderr, flush=True)
+                if verbose:
+                    print(f"[bench] cell {shape} M={m} {mode}", file=sys.stderr, flush=True)
                 r = weights[key].time(mode, stream)
                 out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "GBs": round(r["gbs"]), "frac": round(r["gbs"] / BL.HBM_PEAK_GBS, 4)})
             elif shape == "mlp":      # gate_up -> SiLU-mul -> down of Llama-3-70B as one unit (BL.MlpBlock)
@@ -148,7 +150,8 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                     torch.cuda.empty_cache()
                     weights["mlp"] = BL.MlpBlock(m, dev)
                 blk = weights["mlp"]
-                print(f"[bench] cell mlp M={m} {mode}", file=sys.stderr, flush=True)
+                if verbose:
+                    print(f"[bench] cell mlp M={m} {mode}", file=sys.stderr, flush=True)
                 r = blk.time(mode[4:], stream)
                 pk_peak = BL.BF16_PEAK_TFLOPS if mode == "mlp_exact" else BL.FP8_PEAK_TFLOPS if "mxfp8" in mode else BL.FP4_PEAK_TFLOPS
                 out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "TF": round(r["tflops"], 1), "frac": round(r["tflops"] / pk_peak, 4)})
@@ -169,7 +172,8 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                     weights[(shape, w)] = BL.Weights(w, n, k, 1280, dev)
                 g = BL.Gemm(weights[(shape, w)], m, dtype, dev)
                 sid = g.resolve(mode_sid[mode])
-                print(f"[bench] cell {shape} M={m} {a}x{w} {mode}: 0x{sid:x} {_lib.describe_solution(sid)}", file=sys.stderr, flush=True)
+                if verbose:
+                    print(f"[bench] cell {shape} M={m} {a}x{w} {mode}: 0x{sid:x} {_lib.describe_solution(sid)}", file=sys.stderr, flush=True)
                 r = g.time(mode_sid[mode], stream, reps=7 if hbm else 5)
                 out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2)})
                 if hbm:
@@ -177,15 +181,38 @@ def measure_cells(dev, stream, budget_s: float, sink=None) -> dict:
                 else:
                     out.update({"TF": round(r["tflops"], 1), "frac": round(r["tflops"] / peak[mode], 4)})
                 out["sid"] = f"{sid:x}"
+                out["kernel"] = _lib.describe_solution(sid)
             cells.append(out)
         except Exception as exc:  # noqa: BLE001 -- one cell (e.g. the vendor comparator) must never take the table down
             notes.append(f"{shape} M={m} {a}x{w} {mode} failed: {exc}")
         torch.cuda.empty_cache()
     return {"cells": cells, "cells_notes": notes, "cells_seconds": round(time.time() - t0, 1),
             "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, median of 5-7 replays; "
-                            "frac = GB/s / 8000 (M <= 16) or TFLOPS / 2500 (M = 512; native_mxfp8 / 5000, native_mxfp4 / 10000, both launches "
-                            "timed); sid = the kernel id the call resolved to (petit_describe_solution names it); hipblaslt = vendor dense "
-                            "bf16 GEMM, HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm"}
+                            "rate = GB/s (M <= 16) or TFLOP/s; frac = rate / 8000 GB/s, or / 2500 TFLOP/s (native_mxfp8 / 5000, native_mxfp4 / 10000, "
+                            "both launches timed); hipblaslt = vendor dense bf16 GEMM (HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm); "
+                            "us_min, kernel id and description per cell: gpurun_out/bench_cells_full.json"}
+
+
+COPY_CEILING_GBS = 6290.0      # the guide's measured HBM copy ceiling (MI355X_MICROARCH.md): what a pure stream reaches of the 8 TB/s spec
+
+
+def compact_cells(cells: list) -> dict:
+    """The line's form of the cell table: one short row per cell, and the metric's own 16 cells (bf16 x NVFP4, M in {1, 8, 16, 512},
+    the four Llama-3-70B linears) once more as `metric_cells` -- printed LAST, so that a record which keeps only the tail of stdout
+    keeps them."""
+    rows, metric = [], []
+    for c in cells:
+        rate = c.get("GBs", c.get("TF"))
+        rows.append([c["shape"], c["M"], c["dt"], c["us"], rate, round(c["frac"], 3)])
+        if c["dt"] == "bf16xnv" and c["M"] in (1, 8, 16, 512) and c["shape"] in ("qkv", "o", "gate_up", "down"):
+            row = [c["shape"], c["M"], c["us"], rate, round(c["frac"], 3)]
+            if "GBs" in c:
+                row.append(round(c["GBs"] / COPY_CEILING_GBS, 3))
+            metric.append(row)
+    return {"cells_cols": ["shape", "M", "dtypes mode", "us", "GB/s (M<=16) | TFLOP/s", "frac of 8 TB/s | MFMA peak"], "cells": rows,
+            "metric_cells_cols": ["shape", "M", "us", "GB/s (M<=16) | TFLOP/s", "frac of 8 TB/s | 2.5 PFLOP/s",
+                                  "frac of the 6.29 TB/s copy ceiling (M<=16)"],
+            "metric_cells": metric}
 
 
 def host_overhead(step, n_calls: int = 3000) -> dict:
@@ -216,6 +243,7 @@ def main() -> None:
     ap.add_argument("--no-cells", action="store_true", help="headline only (skip the M x shape table)")
     ap.add_argument("--no-host-overhead", action="store_true", help="skip the eager host-cost measurement (profiling runs)")
     ap.add_argument("--cells-budget-s", type=float, default=170.0)
+    ap.add_argument("--verbose", action="store_true", help="one stderr line per cell (the kernel each call resolved to)")
     ap.add_argument("--cells-child", default="", help=argparse.SUPPRESS)   # internal: run the cell table, append JSON lines to this file
     ap.add_argument("--rotate-mb", type=int, default=1280,
                     help="rotate over at least this many MB of distinct weights; measured on MI355X: per-launch time "
@@ -231,7 +259,7 @@ def main() -> None:
     if args.cells_child:
         torch.cuda.set_device(0)
         with open(args.cells_child, "a") as sink:
-            meta = measure_cells(torch.device("cuda", 0), torch.cuda.Stream(), args.cells_budget_s, sink)
+            meta = measure_cells(torch.device("cuda", 0), torch.cuda.Stream(), args.cells_budget_s, sink, args.verbose)
             meta.pop("cells")
             sink.write(json.dumps({"_meta": meta}) + "\n")
         return
@@ -409,6 +437,7 @@ def main() -> None:
                 line["host_us_per_call"]["package_default"] = "compiled" if petit_kernel._impl is compiled else "ctypes"
         del packed
         torch.cuda.empty_cache()
+        full_cells = None
         if world == 1 and not args.no_cells:
             # the table runs in a CHILD process that reports every finished cell at once: a fault in any one kernel (or in
             # the vendor comparator) costs that cell, never the headline line or the cells already measured
@@ -417,7 +446,8 @@ def main() -> None:
             with tempfile.NamedTemporaryFile("r", suffix=".jsonl", dir=str(ROOT / "gpurun_out") if (ROOT / "gpurun_out").is_dir() else None) as tf:
                 try:
                     rc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cells-child", tf.name, "--cells-budget-s",
-                                         str(args.cells_budget_s)], timeout=args.cells_budget_s + 90, stdout=subprocess.DEVNULL).returncode
+                                         str(args.cells_budget_s)] + (["--verbose"] if args.verbose else []),
+                                        timeout=args.cells_budget_s + 90, stdout=subprocess.DEVNULL).returncode
                 except subprocess.TimeoutExpired:
                     rc = "timeout"
                 cells, meta = [], {}
@@ -427,13 +457,21 @@ def main() -> None:
                         meta = rec["_meta"]
                     else:
                         cells.append(rec)
-                line["cells"] = cells
                 line.update(meta)
                 if rc != 0:
                     line["cells_error"] = f"cell process ended with {rc} after {len(cells)} cells (see stderr)"
+                full_cells = cells
+                try:  # everything a cell measured (us_min, kernel id + description): a side file, not the line
+                    side = ROOT / "gpurun_out" / "bench_cells_full.json"
+                    side.parent.mkdir(exist_ok=True)
+                    side.write_text(json.dumps({"steps": args.steps, "cells": cells}, indent=0))
+                except OSError:
+                    pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a, gs, qs[0], ss[0])
-        print(json.dumps(line), flush=True)
+        if full_cells is not None:
+            line.update(compact_cells(full_cells))   # LAST: the metric's own cells end the line
+        print(json.dumps(line, separators=(",", ":")), flush=True)
 
     if world > 1:
         dist.destroy_process_group()

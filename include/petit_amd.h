@@ -51,12 +51,12 @@ typedef enum petit_data_type {
     PETIT_DTYPE_BF16 = 5,
     PETIT_DTYPE_FP8_E5M2_FNUZ = 6,
     PETIT_DTYPE_MXFP4_E2M1 = 7, /* MXFP4: e8m0 scales, group 32 */
-    /* Extension (not in the reference's enum), as hints->b_type on the MXFP4 entry points: MXFP4 weights whose EVERY e8m0 block scale byte
-     * lies in 114..140 (2^-13 .. 2^13), so that e2m1 x scale is a normal fp16 number -- true of real checkpoints, whose block scales sit within a few
-     * binades of 1.  The caller's promise: nothing checks it, and a scale outside the range over- or underflows in fp16.  With fp16 activations the
-     * library then converts the weights straight to fp16 (one MFMA per fragment, every kernel family: 20-25 % faster at M <= 16, ~2x at M = 512)
-     * instead of the exact bf16 hi / lo split it needs for arbitrary e8m0 scales; with bf16 activations, the native sentinels or a native id it is
-     * the same as PETIT_DTYPE_MXFP4_E2M1.  Kernel ids carry their own element nibble: enumerate them with this type in the hints. */
+    /* Deprecated alias of PETIT_DTYPE_MXFP4_E2M1 (round 3: "MXFP4 whose every e8m0 block scale byte lies in 114..140", a caller's promise that
+     * selected a faster fp16 kernel family).  Nobody has to promise anything any more: with fp16 activations every MXFP4 kernel tests, per wave
+     * and span, the scale bytes it holds anyway, converts the weights straight to fp16 (one MFMA per fragment) while they lie in
+     * PETIT_MXFP4_F16RANGE_SCALE_MIN .. _MAX (2^-13 .. 2^13: e2m1 x scale a normal fp16 number -- every real checkpoint), and finishes its K range
+     * in an exact bf16 hi / lo fallback body from the first byte that does not.  Both bodies are exact, so the value 8 carries no information;
+     * it is accepted wherever PETIT_DTYPE_MXFP4_E2M1 is and treated as it. */
     PETIT_DTYPE_MXFP4_E2M1_F16RANGE = 8
 } petit_data_type;
 #define PETIT_MXFP4_F16RANGE_SCALE_MIN 114
@@ -68,7 +68,7 @@ typedef enum petit_data_type {
  * changes the result. */
 typedef struct petit_solution_hints {
     int32_t a_type; /* PETIT_DTYPE_FP16 or PETIT_DTYPE_BF16 */
-    int32_t b_type; /* PETIT_DTYPE_FP4_E2M1, PETIT_DTYPE_MXFP4_E2M1 or PETIT_DTYPE_MXFP4_E2M1_F16RANGE */
+    int32_t b_type; /* PETIT_DTYPE_FP4_E2M1 or PETIT_DTYPE_MXFP4_E2M1 */
     int32_t c_type; /* must equal a_type */
     int32_t require_high_precision;
 } petit_solution_hints;

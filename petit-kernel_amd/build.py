@@ -29,7 +29,11 @@ if not os.environ.get("PETIT_AMD_NO_KERNARG_PRELOAD"):
 
 
 def sources():
-    return sorted(CSRC.glob("*.hip"))
+    # the slowest translation units first (by the size of their previous object file), so that the tail of a parallel build is short
+    def weight(src: Path) -> int:
+        obj = OBJ / (src.stem + ".o")
+        return -(obj.stat().st_size if obj.exists() else 1 << 30)
+    return sorted(CSRC.glob("*.hip"), key=lambda s: (weight(s), s.name))
 
 
 def deps_mtime() -> float:
@@ -58,6 +62,9 @@ def build(force: bool = False, jobs: int | None = None) -> Path:
     hdr = deps_mtime()
     srcs = sources()
     jobs = jobs or min(len(srcs), os.cpu_count() or 4)
+    for stale in OBJ.glob("*.o"):  # objects of translation units that no longer exist
+        if not (CSRC / (stale.stem + ".hip")).exists():
+            stale.unlink()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(lambda s: compile_one(s, force, hdr), srcs))
     if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):

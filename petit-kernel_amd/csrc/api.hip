@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +25,33 @@
 #include "solution.h"
 
 namespace petit_amd {
+
+// The family tables: the parts exported by the family's translation units, concatenated once (streaming kernels first, as the
+// heuristic and the tuner's reference-kernel choice expect: the plain direct-path kernel is the first entry).
+using PartFn = const SolutionEntry *(*)(int *);
+static const SolutionEntry *concat_parts(std::vector<SolutionEntry> &store, std::initializer_list<PartFn> parts, int *count) {
+    if (store.empty())
+        for (PartFn fn : parts) {
+            int n = 0;
+            const SolutionEntry *e = fn(&n);
+            store.insert(store.end(), e, e + n);
+        }
+    *count = (int)store.size();
+    return store.data();
+}
+#define PETIT_FAMILY_TABLE(fam, ...)                                                                          \
+    const SolutionEntry *solutions_##fam(int *count) {                                                        \
+        static std::vector<SolutionEntry> store;                                                              \
+        static const SolutionEntry *const table = concat_parts(store, {__VA_ARGS__}, count);                  \
+        *count = (int)store.size();                                                                           \
+        return table;                                                                                         \
+    }
+PETIT_FAMILY_TABLE(nv_bf16, solutions_nv_bf16_p1, solutions_nv_bf16_p2, solutions_nv_bf16_p3, solutions_nv_bf16_p4)
+PETIT_FAMILY_TABLE(nv_f16, solutions_nv_f16_p1, solutions_nv_f16_p2, solutions_nv_f16_p3, solutions_nv_f16_p4)
+PETIT_FAMILY_TABLE(mx_bf16, solutions_mx_bf16_p1, solutions_mx_bf16_p2, solutions_mx_bf16_p3, solutions_mx_bf16_p4, solutions_mx_bf16_p5)
+PETIT_FAMILY_TABLE(mx_f16, solutions_mx_f16_p1, solutions_mx_f16_p2, solutions_mx_f16_p3, solutions_mx_f16_p4, solutions_mx_f16_p5)
+#undef PETIT_FAMILY_TABLE
+
 namespace {
 
 struct Family {
@@ -36,11 +64,6 @@ bool family_for(int a_type, int b_type, Family *out) {
     const bool mx = is_mx_type(b_type);
     if (b_type != kDataTypeFp4e2m1 && !mx)
         return false;
-    if (a_type == kDataTypeFp16 && b_type == kDataTypeMxFp4e2m1F16Range) { // the caller's promise: every block scale in 114..140
-        out->entries = solutions_mx_f16r(&out->count);
-        out->elem_b = kElemBMxFp4F16Range, out->mfma = kMfmaFp16;
-        return true;
-    }
     if (a_type == kDataTypeBf16 && !mx) {
         out->entries = solutions_nv_bf16(&out->count);
         out->elem_b = kElemBNvFp4, out->mfma = kMfmaBf16;
@@ -56,7 +79,7 @@ bool family_for(int a_type, int b_type, Family *out) {
         out->elem_b = kElemBMxFp4, out->mfma = kMfmaBf16;
         return true;
     }
-    if (a_type == kDataTypeFp16 && mx) { // not in the reference (gemm_fp4_fp16_grid.cc:55-64 rejects it)
+    if (a_type == kDataTypeFp16 && mx) { // not in the reference (gemm_fp4_fp16_grid.cc:55-64 rejects it); Fp16Mx kernels: fast body + exact fallback
         out->entries = solutions_mx_f16(&out->count);
         out->elem_b = kElemBMxFp4, out->mfma = kMfmaFp16;
         return true;
@@ -138,8 +161,7 @@ bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0; }
 // tools/check_heuristic.py replays it against every swept case.
 double stream_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus) {
     const StreamShape &s = e.shape;
-    const bool split = e.a_type == kDataTypeFp16 && e.fmt == kFmtMx; // hi/lo activations: two MFMAs and two fragments per word
-    const double per_weight = (0.5 + 2.0 * s.mt / s.nt) * (split ? 1.5e-7 : 1e-7); // unpack once per block + fragment loads per (m-tile, n-tile) pair
+    const double per_weight = (0.5 + 2.0 * s.mt / s.nt) * 1e-7; // unpack once per block + fragment loads per (m-tile, n-tile) pair
     const unsigned blocks = (m + 16 * s.mt - 1) / (16 * s.mt);
     const double wgs = (double)blocks * ((n / kTileN + s.nt * s.wn - 1) / (s.nt * s.wn));
     // VALU-bound: a CU that holds two workgroups takes twice as long, one that holds none idles
@@ -152,19 +174,12 @@ double stream_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k
 double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus, unsigned splitk = 1) {
     const StreamShape &s = e.shape;
     const int acc = s.mt * s.nt; // accumulator tiles per wave: 8 = 64x128 / 128x64, 16 = 64x256 / 128x128
-    const bool split = e.a_type == kDataTypeFp16 && e.fmt == kFmtMx; // two MFMAs per fragment, two LDS images
-    double t1, resident;
-    if (split) {
-        t1 = s.mt == 4 && s.nt == 2 ? 1.14 : s.mt == 4 && s.nt == 4 ? 1.67 : s.mt == 8 && s.nt == 2 ? 3.0 : 0.19 * acc + 0.3;
-        resident = acc <= 8 && s.mt <= 4 ? 1.14 : 1.0;
-    } else {
-        t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
-           : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97
-           : s.mt == 4 && s.nt == 5 ? 1.43 : s.mt == 8 && s.nt == 4 ? 1.92 : 0.09 * acc + 0.2; // (64x320: qkv M = 512 91.6 us / 64 steps; 128x256: down 215 us / 112)
-        if (e.fmt == kFmtMx)
-            t1 *= 0.75; // no group-scale multiplies in the unpack
-        resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
-    }
+    double t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
+              : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97
+              : s.mt == 4 && s.nt == 5 ? 1.43 : s.mt == 8 && s.nt == 4 ? 1.92 : 0.09 * acc + 0.2; // (64x320: qkv M = 512 91.6 us / 64 steps; 128x256: down 215 us / 112)
+    if (e.fmt == kFmtMx)
+        t1 *= 0.75; // no group-scale multiplies in the unpack
+    const double resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
     const unsigned per_wg = s.nt * s.wn;
     const double wgs = (double)((m + 16 * s.mt - 1) / (16 * s.mt)) * (double)((n / kTileN + per_wg - 1) / per_wg);
     double rounds = wgs * splitk / (num_cus * resident);
@@ -438,7 +453,7 @@ bool is_auto_id(uint64_t solution_id) { return solution_id == PETIT_SOLUTION_AUT
 // returns) therefore work with mul_mxfp4_a16; the block-floating-point staged kernels, which only exist for
 // bf16 x NVFP4, map to their plain staged twins.
 const SolutionEntry *find_explicit(const Family &fam, uint64_t id) {
-    id = (id & ~((uint64_t)0xf << 28)) | ((uint64_t)fam.elem_b << 28);
+    id = (id & ~((uint64_t)0xf << 28)) | ((uint64_t)fam.elem_b << 28); // (also: round 3's element nibble 3, "MXFP4 with scales in fp16's range", reads as MXFP4)
     const SolutionEntry *e = find_entry(fam, id);
     const unsigned am = (unsigned)(id >> 48) & 0xf;
     // NVFP4-only kernel kinds named on the MXFP4 entry point: the plain staged kernel with the same geometry
@@ -449,23 +464,11 @@ const SolutionEntry *find_explicit(const Family &fam, uint64_t id) {
     return e;
 }
 
-// The weight type a call runs with.  PETIT_DTYPE_MXFP4_E2M1_F16RANGE in hints->b_type (the caller's promise that every e8m0 block scale lies in
-// 114..140) selects the single-MFMA fp16 family -- for fp16 activations and the exact class only; bf16 activations, the native sentinels and explicit
-// native ids run as plain MXFP4 (those kernels are indifferent to the promise).
-int effective_b_type(const petit_solution_hints *hints, int entry_b_type, uint64_t solution_id) {
-    if (!hints || !is_mx_type(entry_b_type))
-        return entry_b_type;
-    if (hints->b_type != kDataTypeMxFp4e2m1F16Range || hints->a_type != kDataTypeFp16)
-        return kDataTypeMxFp4e2m1;
-    const unsigned kind = (unsigned)(solution_id >> 48) & 0xf;
-    if (auto_class(solution_id) != kClassExact || (!is_auto_id(solution_id) && (kind == 9 || kind == 13)))
-        return kDataTypeMxFp4e2m1;
-    return kDataTypeMxFp4e2m1F16Range;
-}
-// (for the entry points that take the type from the hints alone)
-petit_solution_hints effective_hints(const petit_solution_hints *hints, uint64_t solution_id) {
+// PETIT_DTYPE_MXFP4_E2M1_F16RANGE in hints->b_type (round 3: "every e8m0 block scale lies in 114..140") is accepted and means plain MXFP4:
+// the fp16 x MXFP4 kernels test the range themselves (Fp16Mx, device_common.hpp), so the value carries no information any more.
+petit_solution_hints effective_hints(const petit_solution_hints *hints) {
     petit_solution_hints h = *hints;
-    h.b_type = effective_b_type(hints, hints->b_type, solution_id);
+    h.b_type = canonical_b_type(hints->b_type);
     return h;
 }
 
@@ -478,8 +481,9 @@ petit_solution_hints effective_hints(const petit_solution_hints *hints, uint64_t
 int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, unsigned k, uint64_t max_ws, uint64_t *ids, uint64_t *needs,
                     int cap) {
     Family fam;
+    b_type = canonical_b_type(b_type);
     if (!family_for(a_type, b_type, &fam) || !shape_ok(n, k) || m == 0 || (klass != kClassExact && b_type != kDataTypeMxFp4e2m1))
-        return 0; // (the native class: plain MXFP4 -- the range-limited family has no native kernels and needs none)
+        return 0; // (the native class exists for MXFP4 weights only)
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
     int count = 0;
     auto push = [&](const SolutionEntry &e, unsigned sk, bool front) {
@@ -663,21 +667,21 @@ int petit_gemm_mxfp4_fp16_grid(unsigned *c, const unsigned *a, const unsigned *b
                                const float *global_scale, unsigned m, unsigned n, unsigned k,
                                const petit_solution_hints *hints, uint64_t solution_id, void *stream) {
     // the reference forces element_b = MxFp4 into the id (gemm_fp4_fp16_grid.cc:79-95): find_explicit does the same
-    return gemm_impl(effective_b_type(hints, kDataTypeMxFp4e2m1, solution_id), c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, nullptr, 0, stream);
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, nullptr, nullptr, 0, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid_ex(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                   const float *global_scale, unsigned m, unsigned n, unsigned k,
                                   const petit_solution_hints *hints, uint64_t solution_id,
                                   const petit_epilogue *epilogue, void *stream) {
-    return gemm_impl(effective_b_type(hints, kDataTypeMxFp4e2m1, solution_id), c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, nullptr, 0, stream);
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, nullptr, 0, stream);
 }
 
 int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
                                   const float *global_scale, unsigned m, unsigned n, unsigned k,
                                   const petit_solution_hints *hints, uint64_t solution_id,
                                   const petit_epilogue *epilogue, void *workspace, uint64_t workspace_bytes, void *stream) {
-    return gemm_impl(effective_b_type(hints, kDataTypeMxFp4e2m1, solution_id), c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, workspace,
+    return gemm_impl(kDataTypeMxFp4e2m1, c, a, b, scales, global_scale, m, n, k, hints, solution_id, epilogue, workspace,
                      workspace_bytes, stream);
 }
 
@@ -695,7 +699,7 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
     const bool act = epilogue_act(epilogue, &ok);
     if (!ok || !hints)
         return 0;
-    const petit_solution_hints eff = effective_hints(hints, solution_id);
+    const petit_solution_hints eff = effective_hints(hints);
     hints = &eff;
     if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
         return 0;
@@ -758,6 +762,8 @@ int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned coun
         return kErrBadArgument;
     if (hints->c_type != hints->a_type)
         return kErrKernelShape;
+    const petit_solution_hints eff = effective_hints(hints);
+    hints = &eff;
     Family fam;
     if (!family_for(hints->a_type, hints->b_type, &fam))
         return kErrKernelShape;
@@ -821,6 +827,8 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
         return -1;
     if (hints->b_type != kDataTypeFp4e2m1 && !is_mx_type(hints->b_type))
         return -1; // algo_chooser.cc:20-23
+    const petit_solution_hints eff = effective_hints(hints);
+    hints = &eff;
     Family fam;
     unsigned count = 0;
     const unsigned cap = sols ? *n_sols : 0;
@@ -846,7 +854,7 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
     const bool act = epilogue_act(epilogue, &ok);
     if (!ok || !hints)
         return 0;
-    const petit_solution_hints eff = effective_hints(hints, solution_id);
+    const petit_solution_hints eff = effective_hints(hints);
     hints = &eff;
     if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
         return 0;
@@ -977,9 +985,9 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kErrBadArgument;
     const unsigned elem_b = (unsigned)(id >> 28) & 0xf, mfma = (unsigned)(id >> 32) & 0xf;
     const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8 || mfma == kMfmaFp4) ? kDataTypeBf16 : kDataTypeFp16;
-    const int b_type = elem_b == kElemBMxFp4 ? kDataTypeMxFp4e2m1 : elem_b == kElemBMxFp4F16Range ? kDataTypeMxFp4e2m1F16Range : kDataTypeFp4e2m1;
+    const int b_type = (elem_b == kElemBMxFp4 || elem_b == 3u) ? kDataTypeMxFp4e2m1 : kDataTypeFp4e2m1; // (3: round 3's fp16-range nibble)
     Family fam;
-    const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_entry(fam, id) : nullptr;
+    const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_explicit(fam, id) : nullptr;
     if (!e) {
         snprintf(buf, len, "unknown solution 0x%llx", (unsigned long long)id);
         return kErrKernelShape;
@@ -1000,18 +1008,18 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     }
     if (s.am == kWideAm) {
         snprintf(buf, len, "wide32 %sx%s ks%d mb%d np%d waves%d kgroups%d d%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x16 mfma)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : b_type == kDataTypeMxFp4e2m1F16Range ? "mxfp4(f16-range scales)" : "nvfp4", s.ks,
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
                  s.mt, s.nt / 2, s.wn, s.wm == 3 ? 2 : 1, s.d, s.pa, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * (s.wm == 3 ? 2 : 1));
         return kOk;
     }
     if (s.am == kTiledAm) {
         snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d splitk%u  (wg tile %dx%d, %d threads)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : b_type == kDataTypeMxFp4e2m1F16Range ? "mxfp4(f16-range scales)" : "nvfp4", s.ks,
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
                  s.mt, s.nt, s.wn, s.d, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
         return kOk;
     }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",
-             a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : b_type == kDataTypeMxFp4e2m1F16Range ? "mxfp4(f16-range scales)" : "nvfp4", s.ks,
+             a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
              s.mt, s.nt, s.wn, s.wk, s.d, am_rows(s.am), solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt,
              64 * s.wn * s.wk);
     if (s.wm == 2 && s.am < kDecodeAm) // (the 8-row decode kernel also carries warp_partition_m = 2: solution.h)

@@ -32,12 +32,12 @@ enum : int { kAuxDefault = 0, kAuxNt = 2 };
 struct Bf16 {
     using frag = bf16x8;
     static constexpr int kType = kDataTypeBf16;
-    static constexpr bool kSplit = false, kBfp = false;
+    static constexpr bool kBfp = false, kAdaptive = false;
 };
 struct Fp16 {
     using frag = f16x8;
     static constexpr int kType = kDataTypeFp16;
-    static constexpr bool kSplit = false, kBfp = false;
+    static constexpr bool kBfp = false, kAdaptive = false;
 };
 // bf16 activations on the fp16 pipeline (staged path only).  The fp16 unpack of an
 // NVFP4 word is 8 VALU (convert + v_pk_mul_f16) against 12 for bf16 (convert to f32,
@@ -53,18 +53,23 @@ struct Fp16 {
 struct Bf16Bfp {
     using frag = f16x8;
     static constexpr int kType = kDataTypeBf16;
-    static constexpr bool kSplit = false, kBfp = true;
+    static constexpr bool kBfp = true, kAdaptive = false;
 };
 // fp16 activations against MXFP4 weights (a capability the reference does not have:
-// fp4/warp_schedule_fp16.cuh:22-26 static_asserts it away).  e8m0 block scales span
-// 2^-127..2^127, far outside fp16, so the weights are dequantised to bf16 (exact) and
-// every fp16 activation a is split EXACTLY into two bf16 numbers a = hi + lo
-// (hi = the top 8 significant bits, lo = the remaining <= 3): two bf16 MFMAs per
-// fragment, f32 accumulation, no precision lost anywhere.
-struct Fp16Split {
-    using frag = bf16x8;
+// fp4/warp_schedule_fp16.cuh:22-26 static_asserts it away).  e8m0 block scales span 2^-127..2^127, far outside fp16 -- but
+// no real checkpoint's do: when a block scale byte lies in 114..140 (2^-13..2^13), e2m1 x scale is a NORMAL fp16 number
+// (0.5 x 2^-13 = 2^-14 ... 6 x 2^13 = 49152) and v_cvt_scalef32_pk_f16_fp4 produces it exactly with the scale in the
+// convert: 4 VALU per word, one f16 MFMA per fragment.  The kernels DECIDE THIS THEMSELVES, per wave and span, on the scale
+// record they hold anyway (mx_rec_outside_f16: 3 VALU per dword + one ballot per span), so nobody has to promise anything:
+// the first span with a byte outside 114..140 switches the wave, for the rest of its K range, to the fallback body, which
+// is exact for ANY e8m0 scale: weights dequantised to bf16 (exact: bf16 has f32's exponent range) and every fp16 activation
+// fragment split in registers into two bf16 fragments, a = hi + lo exactly (hi = the top 8 significant bits, lo = the
+// remaining <= 3): two bf16 MFMAs per word, f32 accumulation, no precision lost anywhere.  One-way switch = two loops in
+// sequence, never a diamond inside the unrolled span.
+struct Fp16Mx {
+    using frag = f16x8;
     static constexpr int kType = kDataTypeFp16;
-    static constexpr bool kSplit = true, kBfp = false;
+    static constexpr bool kBfp = false, kAdaptive = true;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
@@ -130,9 +135,8 @@ __device__ __forceinline__ bf16x8 unpack_mx(Bf16, unsigned w, float s) {
     return bf16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
 }
 
-__device__ __forceinline__ bf16x8 unpack_mx(Fp16Split, unsigned w, float s) { return unpack_mx(Bf16{}, w, s); }
 // MXFP4 -> fp16 with the block scale in the convert: exact iff every product e2m1 x 2^(s - 127) is a NORMAL fp16 number, i.e. 114 <= s <= 140
-// (0.5 x 2^-13 = 2^-14 ... 6 x 2^13 = 49152).  Only the range-limited family (gemm_mx_f16r.hip: the caller promises that range) is built on it.
+// (0.5 x 2^-13 = 2^-14 ... 6 x 2^13 = 49152).  Only the fast body of the Fp16Mx kernels calls it, after mx_rec_outside_f16 has cleared the span.
 __device__ __forceinline__ f16x8 unpack_mx(Fp16, unsigned w, float s) {
     f16x2 q0 = cvt_fp4_f16<0>(w, s);
     f16x2 q1 = cvt_fp4_f16<1>(w, s);
@@ -140,6 +144,7 @@ __device__ __forceinline__ f16x8 unpack_mx(Fp16, unsigned w, float s) {
     f16x2 q3 = cvt_fp4_f16<3>(w, s);
     return f16x8{q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
 }
+__device__ __forceinline__ f16x8 unpack_mx(Fp16Mx, unsigned w, float s) { return unpack_mx(Fp16{}, w, s); }
 
 // 8 fp16 values -> (hi, lo) bf16 fragments with hi + lo == the fp16 value exactly.
 __device__ __forceinline__ void split_f16(const u32x4 &h, u32x4 &hi, u32x4 &lo) {
@@ -164,6 +169,12 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// Fp16Mx fallback: one weight word (bf16, any scale) against an fp16 activation fragment already split into hi + lo.
+__device__ __forceinline__ f32x4 mfma16_hilo(bf16x8 w, const u32x4 &hi, const u32x4 &lo, f32x4 c) {
+    c = mfma16(w, __builtin_bit_cast(bf16x8, hi), c);
+    return mfma16(w, __builtin_bit_cast(bf16x8, lo), c);
+}
+
 // e4m3 byte SEL of a packed dword -> f32 (OCP e4m3 on gfx950).
 template <int SEL> __device__ __forceinline__ float e4m3_byte(unsigned packed) {
     return __builtin_amdgcn_cvt_f32_fp8((int)packed, SEL);
@@ -179,7 +190,7 @@ __device__ __forceinline__ unsigned pack2(Bf16, float lo, float hi) {
 }
 __device__ __forceinline__ unsigned pack2(Bf16Bfp, float lo, float hi) { return pack2(Bf16{}, lo, hi); }
 __device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi);
-__device__ __forceinline__ unsigned pack2(Fp16Split, float lo, float hi) { return pack2(Fp16{}, lo, hi); }
+__device__ __forceinline__ unsigned pack2(Fp16Mx, float lo, float hi) { return pack2(Fp16{}, lo, hi); }
 __device__ __forceinline__ unsigned pack2(Fp16, float lo, float hi) {
     f16x2 q = __builtin_convertvector(f32x2{lo, hi}, f16x2); // RNE
     return __builtin_bit_cast(unsigned, q);
@@ -357,6 +368,20 @@ __device__ __forceinline__ void tile_scales(const ScaleRec<FMT, KS> &rec, float 
     } else {
         s_lo = s_hi = e8m0_byte<T % 4>(rec.d[T / 4]);
     }
+}
+
+// Fp16Mx: does this lane's MX span record hold a byte outside 114..140?  Per dword x: 140 - b and b - 114 computed for all four
+// bytes at once by two plain 32-bit subtractions (no byte of an in-range dword borrows; a byte that does borrow ends with bit 7
+// set, and what the borrow does to its neighbour can only flag more), OR-ed over the record: every byte in range <=> the top
+// three bits of every byte of both differences are clear (0 <= 140 - b <= 31 and 0 <= b - 114 <= 31  <=>  114 <= b <= 140).
+// Returns non-zero for "outside"; wave-uniform use: __builtin_amdgcn_ballot_w64(bad != 0) != 0.
+template <int KS> __device__ __forceinline__ unsigned mx_rec_outside_f16(const ScaleRec<kFmtMx, KS> &rec, unsigned acc = 0u) {
+#pragma unroll
+    for (int d = 0; d < ScaleRec<kFmtMx, KS>::kDwords; ++d) {
+        const unsigned x = rec.d[d];
+        acc |= (0x8C8C8C8Cu - x) | (x - 0x72727272u);
+    }
+    return acc & (KS >= 4 ? 0xE0E0E0E0u : 0x0000E0E0u); // (KS = 2: a two-byte record, zero-extended by its load)
 }
 
 // Compile-time loop with a constant index (scale-record bytes, ring slots and

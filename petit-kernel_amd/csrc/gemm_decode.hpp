@@ -71,7 +71,7 @@ template <class AT_, int KS_, int NT_, int WK_, int D_, int R_> struct DecodeCfg
     static constexpr int kSets = R == 8 ? 2 : 1;          // masked passes per k-tile
     static_assert(R == 1 || R == 2 || R == 4 || R == 8, "rows: 1, 2, 4 or 8");
     static_assert(KS % D == 0 && KS % TG == 0, "ring depth must divide the span");
-    static_assert(!AT::kSplit && !AT::kBfp, "plain bf16 / fp16 activations");
+    static_assert(!AT::kBfp && !AT::kAdaptive, "plain bf16 / fp16 activations");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
 };
 

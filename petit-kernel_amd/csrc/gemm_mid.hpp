@@ -47,7 +47,8 @@ template <class AT_, int FMT_, int KS_, int NT_, int WN_, int WK_, int D_, int A
     static_assert(AM == 8 || AM == 16, "rows: 8 or 16");
     static_assert(kDma >= 1 && kDma * WN * 4 == AM, "the waves of a K part split a tile into whole KiB loads");
     static_assert(KS % D == 0, "ring depth must divide the span");
-    static_assert(!AT::kSplit && !AT::kBfp, "plain bf16 / fp16 activations");
+    static_assert(!AT::kBfp, "plain bf16 / fp16 activations (or Fp16Mx: fast body + exact fallback, device_common.hpp)");
+    static_assert(!AT::kAdaptive || FMT == kFmtMx, "Fp16Mx: fp16 activations x MXFP4 weights");
     static_assert(kThreads <= 1024 && kSmemU4 * 16 <= 160 * 1024, "workgroup / LDS budget");
 };
 
@@ -219,9 +220,62 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_mid_kernel(const void *arg
                     srec[nt] = srec_next[nt];
             }
         };
-        for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
-            span_body(sp, std::false_type{});
-        span_body(sp_end - 1, std::true_type{});
+        if constexpr (AT::kAdaptive) {
+            // Fp16Mx: the fast body while the span's scale record (this lane's bytes of this wave's n-tiles) lies in 114..140; the first span
+            // that does not switches THIS WAVE to the fallback for the rest of its range -- exact for any e8m0 scale, written for size, not
+            // speed: one k-tile per trip of a rolled loop, the W tile and its scale byte loaded on the spot, weights to bf16, the fp16
+            // fragments split into hi + lo bf16 in registers, two MFMAs per word.  It keeps the workgroup's protocol (its share of the
+            // activation-tile DMA D steps ahead, one barrier per step; every wait is a full drain), so the other waves never notice.
+            auto needs_fallback = [&]() -> bool {
+                unsigned bad = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if ((unsigned)nt < valid_nt)
+                        bad = mx_rec_outside_f16<KS>(srec[nt], bad);
+                return __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+            };
+            unsigned sp = sp_begin;
+            bool fb = needs_fallback();
+            for (; sp + 1 < sp_end && !fb; ++sp) {
+                span_body(sp, std::false_type{});
+                fb = needs_fallback();
+            }
+            if (!fb) {
+                span_body(sp_end - 1, std::true_type{});
+            } else {
+#pragma unroll 1
+                for (unsigned kt = sp * KS; kt < sp_end * KS; ++kt) {
+                    u32x4 af[4], wt[NT];
+                    float sc[NT];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        af[j] = fptr[j][aslot * Cfg::kTileU4];
+                    if (kt + D < sp_end * KS)
+                        dma_a_tile(aslot == 0 ? (unsigned)D : aslot - 1, kt + D);
+                    aslot = aslot + 1 == (unsigned)Cfg::kSlots ? 0u : aslot + 1;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        wt[nt] = buf_load16(w_rsrc, w_voff[nt], kt * kTileBytes, kAuxNt);
+                        const unsigned sb = __builtin_amdgcn_raw_buffer_load_b8(s_rsrc, s_voff[nt] + kt % KS, (kt / KS) * 64 * kRecBytes, kAuxDefault);
+                        sc[nt] = __builtin_bit_cast(float, (sb & 0xffu) << 23);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        u32x4 hi, lo;
+                        split_f16(af[j], hi, lo);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt][0] = mfma16_hilo(unpack_mx(Bf16{}, wt[nt][j], sc[nt]), hi, lo, acc[nt][0]);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        } else {
+            for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+                span_body(sp, std::false_type{});
+            span_body(sp_end - 1, std::true_type{});
+        }
     }
     // barrier count of the spans this part does not have (ragged K split): 1 for the prologue + KS per span
     {

@@ -1,0 +1,8 @@
+// gemm_nv_bf16_p1.hip -- kernel instances, part 1 (streaming kernels, M <= 4 staged or direct; stream_tu.inc): bf16 activations x NVFP4 weights.
+#define PETIT_TU_AT Bf16
+#define PETIT_TU_FMT kFmtNv
+#define PETIT_TU_TABLE solutions_nv_bf16
+#define PETIT_TU_BFP_AT Bf16Bfp
+#define PETIT_TU_DECODE
+#define PETIT_TU_PART 1
+#include "stream_tu.inc"

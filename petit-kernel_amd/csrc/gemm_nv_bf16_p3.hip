@@ -1,7 +1,8 @@
-// gemm_nv_bf16.hip -- streaming-kernel instances: Bf16 activations x Nv FP4 weights.
+// gemm_nv_bf16_p3.hip -- kernel instances, part 3 (decode + shared-tile kernels; stream_tu.inc): bf16 activations x NVFP4 weights.
 #define PETIT_TU_AT Bf16
 #define PETIT_TU_FMT kFmtNv
 #define PETIT_TU_TABLE solutions_nv_bf16
 #define PETIT_TU_BFP_AT Bf16Bfp
 #define PETIT_TU_DECODE
+#define PETIT_TU_PART 3
 #include "stream_tu.inc"

@@ -1,0 +1,7 @@
+// gemm_nv_f16_p1.hip -- kernel instances, part 1 (streaming kernels, M <= 4 staged or direct; stream_tu.inc): fp16 activations x NVFP4 weights.
+#define PETIT_TU_AT Fp16
+#define PETIT_TU_FMT kFmtNv
+#define PETIT_TU_TABLE solutions_nv_f16
+#define PETIT_TU_DECODE
+#define PETIT_TU_PART 1
+#include "stream_tu.inc"

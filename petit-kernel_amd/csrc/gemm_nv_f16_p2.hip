@@ -1,0 +1,7 @@
+// gemm_nv_f16_p2.hip -- kernel instances, part 2 (streaming kernels, 8 / 16 rows staged; stream_tu.inc): fp16 activations x NVFP4 weights.
+#define PETIT_TU_AT Fp16
+#define PETIT_TU_FMT kFmtNv
+#define PETIT_TU_TABLE solutions_nv_f16
+#define PETIT_TU_DECODE
+#define PETIT_TU_PART 2
+#include "stream_tu.inc"

@@ -63,8 +63,7 @@ struct StreamCfg {
     // one staged activation row: SL tiles x 256 B, padded by one 16-byte slot so
     // that the rows a ds_read_b128 lane group touches fall on different banks
     static constexpr int kARowU4 = SL * 16 + 1;
-    static constexpr int kSplitN = AT::kSplit ? 2 : 1;                 // hi / lo images of A
-    static constexpr int kALdsU4 = AM * kARowU4 * kSplitN;             // per wave
+    static constexpr int kALdsU4 = AM * kARowU4;                       // per wave
     static constexpr int kRedItems = WN * MT * NT * 64;                // float4 outputs per workgroup
     static constexpr int kSmemU4 = WN * WK * kALdsU4 + (WK > 1 ? WK * kRedItems : 0);
     static_assert(KS % D == 0, "ring depth must divide the span");
@@ -75,6 +74,7 @@ struct StreamCfg {
     static_assert(AM == 0 || KS % SL == 0, "stage length must divide the span");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
     static_assert(!AT::kBfp || (AM > 0 && KS >= 4 && FMT == 0), "block-floating-point A: staged NVFP4 path only");
+    static_assert(!AT::kAdaptive || FMT == kFmtMx, "Fp16Mx: fp16 activations x MXFP4 weights");
 };
 
 // Scalar kernel arguments, most urgent first (not one GemmArgs struct): with -mllvm -amdgpu-kernarg-preload-count the
@@ -197,6 +197,9 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
             }
         };
         float bfp_up = 1.0f; // 2^sh of this lane's activation row for the span now in LDS
+        // Fp16Mx: wave-uniform "the span whose record is in srec (and every later one of this wave) runs the exact fallback body";
+        // set from the record itself (mx_rec_outside_f16), first after the prologue's loads, then whenever srec advances
+        bool mx_fb = false;
         // Block-floating-point spans are EXACT or not taken at all: a span whose rows all satisfy
         // (smallest non-zero exponent) >= (largest exponent) - 31 converts to fp16 without losing a bit (a bf16 value
         // has 8 significant bits; after the shift its last bit sits at >= 2^-24, fp16's subnormal step, and
@@ -276,14 +279,7 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                     } else {
                         dst = (2 * i + (lane >> 5)) * Cfg::kARowU4 + (lane & 31u);
                     }
-                    if constexpr (AT::kSplit) { // hi image, then lo image AM rows further
-                        u32x4 hi, lo;
-                        split_f16(astage[i], hi, lo);
-                        a_lds[dst] = hi;
-                        a_lds[dst + AM * Cfg::kARowU4] = lo;
-                    } else {
-                        a_lds[dst] = astage[i];
-                    }
+                    a_lds[dst] = astage[i];
                 }
             }
         };
@@ -303,7 +299,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                 wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxNt);
 
         u32x4 afrag[MT][4];
-        u32x4 afrag_lo[AT::kSplit && AM > 0 ? 4 : 1]; // staged split path: the lo image's fragments
         // direct path: ring of PA fragment sets, slot T % PA holds tile T of the span
         u32x4 aring[AM == 0 ? PA : 1][MT][4];
         if constexpr (AM == 0) {
@@ -326,8 +321,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                     afrag[0][j] = u32x4{lane, lane + j, 0x3f803f80u, 0x3f803f80u};
                 else
                     afrag[0][j] = a_lds[a_frag_base + j];
-                if constexpr (AT::kSplit)
-                    afrag_lo[j] = a_lds[a_frag_base + AM * Cfg::kARowU4 + j];
             }
         };
         if constexpr (AM > 0) {
@@ -344,6 +337,55 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
         // sched_barrier pins that order (hipcc otherwise sinks every refill to the end
         // of the span and copies the ring at the back edge, draining the pipeline).
         ScaleRec<FMT, KS> srec_next[NT];
+        // Fp16Mx: is any scale byte of the span now in srec outside 114..140?  (n-tiles past N hold zeros: not looked at)
+        auto mx_span_needs_fallback = [&]() -> bool {
+            if constexpr (AT::kAdaptive) {
+                unsigned bad = 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if ((unsigned)nt < valid_nt)
+                        bad = mx_rec_outside_f16<KS>(srec[nt], bad);
+                return __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+            } else {
+                return false;
+            }
+        };
+        // Fp16Mx fallback, spans [sp_from, sp_end) of this wave: exact for ANY e8m0 scale, written for size, not speed (no checkpoint
+        // should ever get here: DESIGN.md section 3.1): one k-tile per trip of a rolled loop, weights and activation fragments straight
+        // from global / L2 (rows >= M are outside a_rsrc: zeros), the tile's scale byte loaded by itself; weights to bf16 (exact), every
+        // fp16 fragment split into hi + lo bf16 in registers, two bf16 MFMAs per word.  (What the fast body had prefetched is dropped.)
+        auto mx_fallback = [&](const unsigned sp_from) {
+            if constexpr (AT::kAdaptive) {
+#pragma unroll 1
+                for (unsigned kt = sp_from * KS; kt < sp_end * KS; ++kt) {
+                    u32x4 wt[NT], af[MT][4];
+                    float sc[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        wt[nt] = buf_load16(w_rsrc, w_voff[nt], kt * kTileBytes, kAuxNt);
+                        const unsigned sb = __builtin_amdgcn_raw_buffer_load_b8(s_rsrc, s_voff[nt] + kt % KS, (kt / KS) * 64 * kRecBytes, kAuxDefault);
+                        sc[nt] = __builtin_bit_cast(float, (sb & 0xffu) << 23);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            af[mt][j] = buf_load16(a_rsrc, a_voff[mt] + j * 16, kt * 256, kAuxDefault);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            u32x4 hi, lo;
+                            split_f16(af[mt][j], hi, lo);
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt][0] = mfma16_hilo(unpack_mx(Bf16{}, wt[nt][j], sc[nt]), hi, lo, acc[mt][nt][0]);
+                        }
+                }
+            } else {
+                (void)sp_from;
+            }
+        };
         auto span_body = [&](const unsigned sp, auto last_c, auto fb_c) {
             constexpr bool kLast = decltype(last_c)::value;
             // kFb: this span of a block-floating-point kernel holds raw bf16 activations (see write_a_stage)
@@ -367,7 +409,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                 // activation fragments: this step's from LDS (staged path), or the next
                 // step's straight from L2 (direct path)
                 u32x4 anext[MT][4];
-                u32x4 anext_lo[AT::kSplit && AM > 0 ? 4 : 1];
                 // does the next tile live in the stage that is in LDS now?
                 constexpr bool kNextInStage = (T + 1 < KS) && ((T + 1) % SL != 0);
                 if constexpr (AM > 0) {
@@ -377,8 +418,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             anext[0][j] = (ABL & 1) ? afrag[0][j] : a_lds[a_frag_base + ((T + 1) % SL) * 16 + j];
-                            if constexpr (AT::kSplit)
-                                anext_lo[j] = a_lds[a_frag_base + AM * Cfg::kARowU4 + ((T + 1) % SL) * 16 + j];
                         }
                         __builtin_amdgcn_sched_barrier(0); // keep the reads at the top of the step
                     }
@@ -389,15 +428,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             afrag[mt][j] = aring[T % PA][mt][j];
-                }
-                // direct path with fp16-split activations: split this step's fragments once
-                u32x4 asplit_hi[AT::kSplit && AM == 0 ? MT : 1][4], asplit_lo[AT::kSplit && AM == 0 ? MT : 1][4];
-                if constexpr (AT::kSplit && AM == 0) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            split_f16(afrag[mt][j], asplit_hi[mt][j], asplit_lo[mt][j]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -420,12 +450,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                             if constexpr (ABL & 4) {
                                 const u32x4 wb = __builtin_bit_cast(u32x4, wf), ab = afrag[mt][j];
                                 a += __builtin_bit_cast(f32x4, wb ^ ab);
-                            } else if constexpr (AT::kSplit && AM > 0) {
-                                a = mfma16(wf, __builtin_bit_cast(FragX, afrag[mt][j]), a);
-                                a = mfma16(wf, __builtin_bit_cast(FragX, afrag_lo[j]), a);
-                            } else if constexpr (AT::kSplit) {
-                                a = mfma16(wf, __builtin_bit_cast(FragX, asplit_hi[mt][j]), a);
-                                a = mfma16(wf, __builtin_bit_cast(FragX, asplit_lo[mt][j]), a);
                             } else
                                 a = mfma16(wf, __builtin_bit_cast(FragX, afrag[mt][j]), a);
                         }
@@ -453,11 +477,6 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         afrag[0][j] = anext[0][j];
-                    if constexpr (AT::kSplit) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            afrag_lo[j] = anext_lo[j];
-                    }
                 }
                 if constexpr (AM > 0 && SL < KS && (T + 1) % SL == 0 && (T + 1 < KS || !kLast)) {
                     // stage boundary inside (or at the end of) the span: every fragment of the old
@@ -491,9 +510,21 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     srec[nt] = srec_next[nt];
+                if constexpr (AT::kAdaptive)
+                    mx_fb = mx_span_needs_fallback();
             }
         };
-        if constexpr (AT::kBfp) {
+        if constexpr (AT::kAdaptive) {
+            // fast spans first; from the first span whose record holds a scale outside fp16's safe range the exact fallback body
+            mx_fb = mx_span_needs_fallback();
+            unsigned sp = sp_begin;
+            for (; sp + 1 < sp_end && !mx_fb; ++sp)
+                span_body(sp, std::false_type{}, std::false_type{});
+            if (!mx_fb)
+                span_body(sp_end - 1, std::true_type{}, std::false_type{});
+            else
+                mx_fallback(sp);
+        } else if constexpr (AT::kBfp) {
             // exact block-floating-point spans first; from the first span that fails the range check (its flag is set
             // by the write_a_stage that put it in LDS: the prologue's, or the previous span's) the bf16 pipeline
             unsigned sp = sp_begin;

@@ -39,19 +39,17 @@ template <class AT_, int FMT_, int KS_, int MT_, int NTW_, int WAVES_, int D_> s
     // ds_write; probed in tools/probes/lds_dma_probe.hip: lane i of a wave-load lands at base + 16 i, out-of-range
     // lanes write zeros).  That forces lane-linear placement, so rows are 16 units with an XOR swizzle instead of
     // a pad: unit u of row r sits at position u ^ (r % 16), and the 16 rows a fragment read touches hit 16
-    // different bank groups.  The fp16 x MXFP4 split needs VALU on the way in and keeps the padded layout.
-    static constexpr bool kDma = !AT::kSplit;
-    static constexpr int kRowU4 = kDma ? 16 : 17;         // 16 units of 16 B (+ 1 pad: bank spread)
-    static constexpr int kImgU4 = BM * kRowU4;            // one A tile image
-    // fp16 x MXFP4: the staging threads split each fp16 activation ONCE into two bf16 (hi + lo, exact), and the
-    // tile lives in LDS as two images; every weight fragment then meets both (two MFMAs instead of one)
-    static constexpr int kBufU4 = kImgU4 * (AT::kSplit ? 2 : 1);
+    // different bank groups.
+    static constexpr int kRowU4 = 16;                     // 16 units of 16 B
+    static constexpr int kBufU4 = BM * kRowU4;            // one A tile
     static constexpr int kUnitsPerThread = BM * 16 / kThreads;
     // 64 accumulator registers + direct-to-LDS staging fit two waves per SIMD; hipcc lands on 260 VGPRs unless told
-    static constexpr int kMinWavesPerSimd = (kDma && MT == 8 && NTW == 2) ? 2 : 1;
+    static constexpr int kMinWavesPerSimd = (MT == 8 && NTW == 2) ? 2 : 1;
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert((BM * 16) % kThreads == 0, "A tile must split evenly over the workgroup");
     static_assert(2 * kBufU4 * 16 <= 160 * 1024, "LDS budget");
+    static_assert(!AT::kBfp, "plain bf16 / fp16 activations (or Fp16Mx: the fast / fallback pair of device_common.hpp)");
+    static_assert(!AT::kAdaptive || FMT == kFmtMx, "Fp16Mx: fp16 activations x MXFP4 weights");
 };
 
 template <class Cfg>
@@ -61,7 +59,6 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
     constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NTW = Cfg::NTW, WAVES = Cfg::WAVES, D = Cfg::D;
     constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
     constexpr unsigned kOob = 0x80000000u;
-    constexpr int UPT = Cfg::kUnitsPerThread;
 
     __shared__ u32x4 smem[2 * Cfg::kBufU4];
 
@@ -112,47 +109,28 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
         w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
         s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
     }
-    // A staging: unit u = tid + i*kThreads -> row u/16, 16-byte column u%16 (a row's 256 B are
-    // read by 16 consecutive lanes: full lines)
-    unsigned a_g_voff[UPT], a_l_idx[UPT];
-#pragma unroll
-    for (int i = 0; i < UPT; ++i) {
-        const unsigned u = tid + i * Cfg::kThreads, row = u >> 4, col = u & 15u;
-        a_g_voff[i] = row * p.k * 2 + col * 16; // rows >= M fall out of range -> zeros
-        a_l_idx[i] = row * Cfg::kRowU4 + col;
-    }
-    const unsigned a_frag_base = r * Cfg::kRowU4 + g * 4; // + mt*16*kRowU4 + j
     // direct-to-LDS staging: wave-load i of this wave covers rows 4*(i*WAVES + wave) .. +3; lane l -> row + l/16,
     // position l%16, which receives unit (l%16) ^ (row%16) of that row
     constexpr int kDmaLoads = Cfg::BM * 16 / 64 / WAVES; // wave-loads per wave per tile
     // one VGPR: wave-load i differs from wave-load 0 only by 4*WAVES whole rows, a multiple of 16, so the swizzle
     // term is the same and the row step rides in the SGPR offset
-    static_assert(!Cfg::kDma || (4 * WAVES) % 16 == 0, "direct-to-LDS staging: wave-loads must step by whole 16-row groups");
+    static_assert((4 * WAVES) % 16 == 0, "direct-to-LDS staging: wave-loads must step by whole 16-row groups");
     const unsigned dma_row0 = wave * 4 + (lane >> 4);
     const unsigned dma_voff = dma_row0 * p.k * 2 + (((lane & 15u) ^ (dma_row0 & 15u)) * 16); // rows >= M: out of range -> zeros
     auto dma_a_tile = [&](u32x4 *dst, unsigned kt) {
-        if constexpr (Cfg::kDma) {
 #pragma unroll
-            for (int i = 0; i < kDmaLoads; ++i) {
+        for (int i = 0; i < kDmaLoads; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass knows neither the builtin nor the LDS address space)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void *)(dst + (i * WAVES + wave) * 64),
-                                                         16, dma_voff, i * (4 * WAVES) * p.k * 2 + kt * 256, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void *)(dst + (i * WAVES + wave) * 64),
+                                                     16, dma_voff, i * (4 * WAVES) * p.k * 2 + kt * 256, 0, 0);
 #else
-                (void)dst, (void)kt;
+            (void)dst, (void)kt;
 #endif
-            }
         }
     };
 
     // --- prologue
-    u32x4 astage[Cfg::kDma ? 1 : UPT];
-    if constexpr (Cfg::kDma) {
-        dma_a_tile(smem, kt_begin); // (kt_begin is even: KS is, so the first tile lands in buffer 0)
-    } else {
-#pragma unroll
-        for (int i = 0; i < UPT; ++i)
-            astage[i] = buf_load16(a_rsrc, a_g_voff[i], kt_begin * 256, kAuxDefault);
-    }
+    dma_a_tile(smem, kt_begin); // (kt_begin is even: KS is, so the first tile lands in buffer 0)
     ScaleRec<FMT, KS> srec[NTW], srec_next[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt)
@@ -163,24 +141,23 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
             wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxDefault);
-    auto store_a_tile = [&](u32x4 *dst) {
-        if constexpr (Cfg::kDma)
-            return; // already on its way into LDS
-#pragma unroll
-        for (int i = 0; i < (Cfg::kDma ? 0 : UPT); ++i) {
-            if constexpr (AT::kSplit) {
-                u32x4 hi, lo;
-                split_f16(astage[i], hi, lo);
-                dst[a_l_idx[i]] = hi;
-                dst[a_l_idx[i] + Cfg::kImgU4] = lo;
-            } else {
-                dst[a_l_idx[i]] = astage[i];
-            }
-        }
-    };
-    store_a_tile(smem);
     __syncthreads();
 
+    // Fp16Mx: is any scale byte of the span now in srec outside 114..140?  Wave-uniform; the first such span switches THIS WAVE to the
+    // fallback loop below for the rest of its K slice
+    auto mx_span_needs_fallback = [&]() -> bool {
+        if constexpr (AT::kAdaptive) {
+            unsigned bad = 0;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                if ((unsigned)nt < valid_nt)
+                    bad = mx_rec_outside_f16<KS>(srec[nt], bad);
+            return __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+        } else {
+            return false;
+        }
+    };
+    bool mx_fb = mx_span_needs_fallback();
     auto span_body = [&](const unsigned sp, auto last_c) {
         constexpr bool kLast = decltype(last_c)::value;
         const unsigned kt0 = sp * KS;
@@ -198,15 +175,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
             const u32x4 *const a_cur = smem + ((kt & 1u) ? Cfg::kBufU4 : 0);
             u32x4 *const a_nxt = smem + ((kt & 1u) ? 0 : Cfg::kBufU4);
             // next step's A tile: global -> registers now, LDS after this step's reads
-            if constexpr (kNextA) {
-                if constexpr (Cfg::kDma) {
-                    dma_a_tile(a_nxt, kt + 1); // everybody left a_nxt at the barrier that ended the previous step
-                } else {
-#pragma unroll
-                    for (int i = 0; i < UPT; ++i)
-                        astage[i] = buf_load16(a_rsrc, a_g_voff[i], (kt + 1) * 256, kAuxDefault);
-                }
-            }
+            if constexpr (kNextA)
+                dma_a_tile(a_nxt, kt + 1); // everybody left a_nxt at the barrier that ended the previous step
             // unpack this step's weight words once
             Frag wf[NTW][4];
 #pragma unroll
@@ -232,44 +202,77 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
             // whole L2 / HBM latency.  Only for the small tiles: with >= 64 accumulator registers the pinned
             // loads cost the second wave per SIMD, which hides that latency better (measured both ways:
             // 64x128 tiles +7 % at M = 256, 128x128 tiles -12 % at M = 512 / 2048).
-            if constexpr (MT * NTW <= 8 || Cfg::kDma)
-                __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
             // every m-tile: 4 fragments from LDS, 4*NTW MFMAs
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                u32x4 af[4], af_lo[AT::kSplit ? 4 : 1];
+                u32x4 af[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (Cfg::kDma)
-                        af[j] = a_cur[(mt * 16 + r) * 16 + ((g * 4 + j) ^ r)];
-                    else
-                        af[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j];
-                    if constexpr (AT::kSplit)
-                        af_lo[j] = a_cur[a_frag_base + mt * 16 * Cfg::kRowU4 + j + Cfg::kImgU4];
-                }
+                for (int j = 0; j < 4; ++j)
+                    af[j] = a_cur[(mt * 16 + r) * 16 + ((g * 4 + j) ^ r)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) // j outer: consecutive MFMAs hit different accumulators
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
+                    for (int nt = 0; nt < NTW; ++nt)
                         acc[mt][nt] = mfma16(wf[nt][j], __builtin_bit_cast(Frag, af[j]), acc[mt][nt]);
-                        if constexpr (AT::kSplit)
-                            acc[mt][nt] = mfma16(wf[nt][j], __builtin_bit_cast(Frag, af_lo[j]), acc[mt][nt]);
-                    }
             }
-            if constexpr (kNextA) {
-                store_a_tile(a_nxt);
+            if constexpr (kNextA)
                 __syncthreads();
-            }
         });
         if constexpr (!kLast) {
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
                 srec[nt] = srec_next[nt];
+            if constexpr (AT::kAdaptive)
+                mx_fb = mx_span_needs_fallback();
         }
     };
-    for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
-        span_body(sp, std::false_type{});
-    span_body(sp_end - 1, std::true_type{});
+    if constexpr (AT::kAdaptive) {
+        unsigned sp = sp_begin;
+        for (; sp + 1 < sp_end && !mx_fb; ++sp)
+            span_body(sp, std::false_type{});
+        if (!mx_fb) {
+            span_body(sp_end - 1, std::true_type{});
+        } else {
+            // Fp16Mx fallback, spans [sp, sp_end): exact for any e8m0 scale, written for size, not speed (device_common.hpp): one k-tile per
+            // trip of a rolled loop, the W tiles and their scale bytes loaded on the spot, weights to bf16, every fp16 fragment split into
+            // hi + lo bf16 in registers, two MFMAs per word.  It keeps the workgroup's protocol -- its share of the next activation tile's
+            // DMA at the top of the step, one barrier per step -- so the waves still in the fast body never notice.
+            const unsigned kt_end = sp_end * KS;
+#pragma unroll 1
+            for (unsigned kt = sp * KS; kt < kt_end; ++kt) {
+                const u32x4 *const a_cur = smem + ((kt & 1u) ? Cfg::kBufU4 : 0);
+                if (kt + 1 < kt_end)
+                    dma_a_tile(smem + ((kt & 1u) ? 0 : Cfg::kBufU4), kt + 1);
+                bf16x8 wb[NTW][4];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const u32x4 wt = buf_load16(w_rsrc, w_voff[nt], kt * kTileBytes, kAuxDefault);
+                    const unsigned sb = __builtin_amdgcn_raw_buffer_load_b8(s_rsrc, s_voff[nt] + kt % KS, (kt / KS) * 64 * kRecBytes, kAuxDefault);
+                    const float sc = __builtin_bit_cast(float, (sb & 0xffu) << 23);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        wb[nt][j] = unpack_mx(Bf16{}, wt[j], sc);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        u32x4 hi, lo;
+                        split_f16(a_cur[(mt * 16 + r) * 16 + ((g * 4 + j) ^ r)], hi, lo);
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            acc[mt][nt] = mfma16_hilo(wb[nt][j], hi, lo, acc[mt][nt]);
+                    }
+                if (kt + 1 < kt_end)
+                    __syncthreads();
+            }
+        }
+    } else {
+        for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+            span_body(sp, std::false_type{});
+        span_body(sp_end - 1, std::true_type{});
+    }
 
     if (gridDim.z > 1) { // K split across workgroups: fp32 partial tile -> this slice's slab
 #pragma unroll

@@ -91,7 +91,8 @@ template <class AT_, int FMT_, int KS_, int MB_, int NP_, int WAVES_, int D_, in
     static constexpr int kSmemU4 = KG * NBUF * kBufU4 > kRedU4 ? KG * NBUF * kBufU4 : kRedU4;
     static_assert(KG == 1 || KG == 2, "one or two K groups");
     static_assert(PF == 1 || PF == 2, "prefetch distance 1 or 2");
-    static_assert(!AT::kSplit && !AT::kBfp, "plain 16-bit activations only");
+    static_assert(!AT::kBfp, "plain bf16 / fp16 activations (or Fp16Mx: fast body + exact fallback, device_common.hpp)");
+    static_assert(!AT::kAdaptive || FMT == kFmtMx, "Fp16Mx: fp16 activations x MXFP4 weights");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert((BM * 16) % (64 * WAVES) == 0 && (4 * WAVES) % 16 == 0, "A tile must split into whole 16-row groups per wave-load");
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
@@ -183,6 +184,35 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
             dst[mb] = a_cur[mb * 32 * 16 + frag_row + ((unsigned)(8 * q + 4 * h + j) ^ frag_swz)];
     };
 
+    // Fp16Mx: this kernel unpacks one step AHEAD of its MFMAs, so a switch between the fast and the fallback body in mid-stream would need
+    // a step that is half of each.  The wave decides ONCE, up front, for its whole K slice instead: the records of one n-tile over the spans
+    // [sp_begin, sp_end) are one contiguous byte range, scanned 16 bytes per lane (a few independent loads, issued ahead of the prologue's
+    // own and answered in the same round trip).
+    bool mx_fb = false;
+    if constexpr (AT::kAdaptive) {
+        const unsigned range = (sp_end - sp_begin) * 64u * kRecBytes; // bytes of one n-tile's records in this slice
+        unsigned bad = 0;
+#pragma unroll
+        for (int nt = 0; nt < 2 * NP; ++nt) {
+            if ((unsigned)nt >= valid_nt)
+                continue;
+            const unsigned row0 = s_voff[nt] - lane * kRecBytes + sp_begin * 64u * kRecBytes;
+#pragma unroll 4
+            for (unsigned base = 0; base < range; base += 1024u) {
+                const unsigned off = base + lane * 16u;
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(s_rsrc, off < range ? row0 + off : kOob, 0, kAuxDefault));
+                unsigned t = 0;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned x = v[d];
+                    t |= (0x8C8C8C8Cu - x) | (x - 0x72727272u); // mx_rec_outside_f16, device_common.hpp
+                }
+                bad |= off < range ? t : 0u;
+            }
+        }
+        mx_fb = __builtin_amdgcn_ballot_w64((bad & 0xE0E0E0E0u) != 0) != 0;
+    }
+
     // --- prologue.  A tiles live in buffer (k-tile index relative to the slice) % NBUF.
     const unsigned kt_end = sp_end * KS;
     dma_a_tile(smem, kt_begin);
@@ -190,6 +220,61 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
         if (kt_begin + 1 < kt_end)
             dma_a_tile(smem + Cfg::kBufU4, kt_begin + 1);
     }
+    if (AT::kAdaptive && mx_fb) {
+        // Fp16Mx fallback for this wave's whole K slice: exact for any e8m0 scale, written for size, not speed (device_common.hpp).  One k-tile
+        // per trip of a rolled loop: the pair's two W tiles loaded on the spot and merged as in the fast body, the scale bytes loaded by
+        // themselves (lane (n, h) of the merged operand P1 / P2 needs the byte of row n % 16 of tile n / 16, k-chunk h / 2 + h: the lane
+        // 16 (2 q + h) + n % 16 of that tile's record), weights to bf16, every fp16 fragment split into hi + lo bf16 in registers, two
+        // MFMAs per word.  It keeps the workgroup's protocol: its share of the activation-tile DMA PF steps ahead, one barrier per step.
+        if constexpr (AT::kAdaptive) {
+            __syncthreads(); // the prologue's barrier: tile kt_begin is in buffer 0
+            unsigned rel = 0; // (k-tile index relative to the slice) % NBUF
+#pragma unroll 1
+            for (unsigned kt = kt_begin; kt < kt_end; ++kt) {
+                const u32x4 *const a_cur = smem + rel * Cfg::kBufU4;
+                if constexpr (PF == 1) {
+                    if (kt + 1 < kt_end)
+                        dma_a_tile(smem + (rel ^ 1u) * Cfg::kBufU4, kt + 1);
+                } else {
+                    dma_a_tile(smem + (rel == 0 ? 2u : rel - 1) * Cfg::kBufU4, kt + 2); // (rel + 2) % 3; past K: zeros nobody reads
+                }
+#pragma unroll
+                for (int np = 0; np < NP; ++np) {
+                    const u32x4 x = buf_load16(w_rsrc, w_voff[2 * np], kt * kTileBytes, kAuxDefault);
+                    const u32x4 y = buf_load16(w_rsrc, w_voff[2 * np + 1], kt * kTileBytes, kAuxDefault);
+                    float sc[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        // lanes 0-15 / 16-31 / 32-47 / 48-63 of P(q+1): [X.g(2q) Y.g(2q) X.g(2q+1) Y.g(2q+1)]
+                        const unsigned tile = (lane >> 4) & 1u, src_lane = 16u * (2u * q + (lane >> 5)) + (lane & 15u);
+                        const unsigned voff = s_voff[2 * np] == kOob ? kOob : s_voff[2 * np] - lane * kRecBytes + src_lane * kRecBytes + kt % KS;
+                        const unsigned voff_y = s_voff[2 * np + 1] == kOob ? kOob : s_voff[2 * np + 1] - lane * kRecBytes + src_lane * kRecBytes + kt % KS;
+                        const unsigned sb = __builtin_amdgcn_raw_buffer_load_b8(s_rsrc, tile ? voff_y : voff, (kt / KS) * 64 * kRecBytes, kAuxDefault);
+                        sc[q] = __builtin_bit_cast(float, (sb & 0xffu) << 23);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned p[2];
+                        merge_tiles(x[j], y[j], p[0], p[1]);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const bf16x8 wb = unpack_mx(Bf16{}, p[q], sc[q]);
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb) {
+                                u32x4 hi, lo;
+                                split_f16(a_cur[mb * 32 * 16 + frag_row + ((unsigned)(8 * q + 4 * h + j) ^ frag_swz)], hi, lo);
+                                acc[mb][np] = mfma32(wb, __builtin_bit_cast(bf16x8, hi), acc[mb][np]);
+                                acc[mb][np] = mfma32(wb, __builtin_bit_cast(bf16x8, lo), acc[mb][np]);
+                            }
+                        }
+                    }
+                }
+                if (kt + 1 < kt_end)
+                    __syncthreads();
+                rel = rel + 1 == (unsigned)NBUF ? 0u : rel + 1;
+            }
+        }
+    } else {
     // scale records, merged per pair like the weight words: rec[np][0] serves P1, rec[np][1] serves P2
     ScaleRec<FMT, KS> rec[NP][2], rec_next[NP][2];
     auto load_recs = [&](ScaleRec<FMT, KS> (*dst)[2], unsigned sp) {
@@ -359,6 +444,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
     for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
         span_body(sp, std::false_type{});
     span_body(sp_end - 1, std::true_type{});
+    } // (fast body)
 
     if constexpr (KG == 2) {
         // a group with fewer spans than its partner keeps the partner's barrier count (a span is KS barriers: the prologue's stands in for

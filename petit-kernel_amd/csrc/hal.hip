@@ -75,6 +75,14 @@ std::once_flag g_override_once;
 std::mutex g_rows_mutex;
 std::atomic<uint64_t> g_generation{1};
 
+// rows written by round 3 may carry b_type 8 / element nibble 3 ("MXFP4 with scales in fp16's range"): plain MXFP4 now (petit_internal.h)
+TunedEntry canonical_row(TunedEntry e) {
+    e.b_type = canonical_b_type(e.b_type);
+    if (((e.solution >> 28) & 0xf) == 3)
+        e.solution = (e.solution & ~((uint64_t)0xf << 28)) | ((uint64_t)2 << 28);
+    return e;
+}
+
 void load_override() {
     const char *path = getenv("PETIT_AMD_TUNE_FILE");
     if (!path || !*path)
@@ -91,7 +99,7 @@ void load_override() {
         unsigned long long sol = 0;
         if (sscanf(line, "%d %d %u %u %u %u %llx", &e.a_type, &e.b_type, &e.n, &e.k, &e.m_lo, &e.m_hi, &sol) == 7) {
             e.solution = sol;
-            g_override.push_back(e); // (a row naming a native-FP4 kernel lands in the native class by its id: never a plain default)
+            g_override.push_back(canonical_row(e)); // (a row naming a native-FP4 kernel lands in the native class by its id: never a plain default)
         }
     }
     fclose(f);
@@ -120,7 +128,8 @@ int solution_class(uint64_t solution) {
 
 uint64_t tuned_generation() { return g_generation.load(std::memory_order_acquire); }
 
-void tuned_insert(const TunedEntry &e) {
+void tuned_insert(const TunedEntry &row) {
+    const TunedEntry e = canonical_row(row);
     std::call_once(g_override_once, load_override);
     {
         std::lock_guard<std::mutex> lock(g_rows_mutex);
@@ -160,6 +169,7 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
     }();
     if (disabled)
         return 0;
+    b_type = canonical_b_type(b_type);
     std::call_once(g_override_once, load_override);
     {
         std::lock_guard<std::mutex> lock(g_rows_mutex);

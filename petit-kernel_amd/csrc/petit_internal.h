@@ -29,12 +29,13 @@ enum DataType : int {
     kDataTypeBf16 = 5,
     kDataTypeFp8e5m2Fnuz = 6,
     kDataTypeMxFp4e2m1 = 7,
-    // extension (not in the reference's enum): MXFP4 whose every e8m0 block scale lies in 114..140, so that e2m1 x scale is a normal fp16 number
-    // (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h): fp16 activations then take the single-MFMA family (gemm_mx_f16r.hip)
+    // round 3's extension "MXFP4 whose every e8m0 block scale lies in 114..140" (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h): still
+    // accepted, and means plain MXFP4 -- the fp16 kernels test the range themselves (Fp16Mx, device_common.hpp), so there is nothing to promise
     kDataTypeMxFp4e2m1F16Range = 8,
 };
 
 constexpr bool is_mx_type(int b_type) { return b_type == kDataTypeMxFp4e2m1 || b_type == kDataTypeMxFp4e2m1F16Range; }
+constexpr int canonical_b_type(int b_type) { return b_type == kDataTypeMxFp4e2m1F16Range ? (int)kDataTypeMxFp4e2m1 : b_type; }
 
 struct GemmArgs {
     void *c;            // [m][n] 16-bit, row-major

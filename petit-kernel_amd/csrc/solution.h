@@ -50,7 +50,7 @@
 namespace petit_amd {
 
 enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
-enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u, kElemBMxFp4F16Range = 3u };
+enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u }; // (3 was round 3's "MXFP4, scales promised in fp16's range": read as 2 now, find_explicit in api.hip)
 enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u, kMfmaFp4 = 6u, kMfmaFp4ActFp16 = 6u | 8u };
 
 struct StreamShape {
@@ -114,12 +114,24 @@ struct SolutionEntry {
     LaunchGroupedFn launch_grouped = nullptr; // the decode and the staged streaming kernels have one (M <= 16)
 };
 
-// one table per (activation type, weight format) translation unit
+// one table per (activation type, weight format) family, concatenated once (api.hip) from the parts its translation units export
+// (stream_tu.inc: gemm_<family>_p<part>.hip)
 const SolutionEntry *solutions_nv_bf16(int *count);
 const SolutionEntry *solutions_nv_f16(int *count);
 const SolutionEntry *solutions_mx_bf16(int *count);
-const SolutionEntry *solutions_mx_f16(int *count);
-const SolutionEntry *solutions_mx_f16r(int *count); // fp16 x MXFP4 with block scales in the fp16-safe range (gemm_mx_f16r.hip)
+const SolutionEntry *solutions_mx_f16(int *count); // Fp16Mx kernels (device_common.hpp)
+#define PETIT_DECLARE_PARTS(fam)                      \
+    const SolutionEntry *solutions_##fam##_p1(int *); \
+    const SolutionEntry *solutions_##fam##_p2(int *); \
+    const SolutionEntry *solutions_##fam##_p3(int *); \
+    const SolutionEntry *solutions_##fam##_p4(int *);
+PETIT_DECLARE_PARTS(nv_bf16)
+PETIT_DECLARE_PARTS(nv_f16)
+PETIT_DECLARE_PARTS(mx_bf16)
+PETIT_DECLARE_PARTS(mx_f16)
+#undef PETIT_DECLARE_PARTS
+const SolutionEntry *solutions_mx_bf16_p5(int *); // native FP4 MFMA kernels: MXFP4 weights only
+const SolutionEntry *solutions_mx_f16_p5(int *);
 // the activation quantiser of the 32x32x64 native kernels, stand-alone (gemm_mx_{bf16,f16}.hip): format 8 = MXFP8, 4 = MXFP4
 int quantize32_bf16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);
 int quantize32_f16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);

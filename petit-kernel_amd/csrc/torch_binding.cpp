@@ -21,7 +21,6 @@ namespace {
 
 constexpr int64_t kLayoutN = 16, kLayoutM = 128, kPack = 8; // fp4.cc:17-19
 constexpr int kCxxFp4 = 3, kCxxFp16 = 4, kCxxBf16 = 5, kCxxMxFp4 = 7; // quantization/types.h:4-13
-constexpr int kCxxMxFp4F16Range = PETIT_DTYPE_MXFP4_E2M1_F16RANGE;       // extension: every e8m0 scale in 114..140 (petit_amd.h)
 
 void *stream_of(const at::Tensor &t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
 
@@ -74,8 +73,7 @@ at::Tensor process_mxfp4_scales(const at::Tensor &s, int64_t n, int64_t k) { ret
 
 // activation: 0 none, 1 silu_mul (PETIT_ACTIVATION_*)
 at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::Tensor &s, const at::Tensor &global_scale, int64_t size_m,
-                   int64_t size_n, int64_t size_k, int64_t solution_id, const std::optional<at::Tensor> &bias, int64_t activation,
-                   bool f16_range = false) {
+                   int64_t size_n, int64_t size_k, int64_t solution_id, const std::optional<at::Tensor> &bias, int64_t activation) {
     // (check order as in the reference's MulNvFp4A16 / MulMxFp4A16, fp4.cc:163-260: the scale / weight tensor contracts first)
     if (mx) {
         TORCH_CHECK(B.dim() == 2 && B.size(0) == size_n / kLayoutN, "B.size(0) = ", B.size(0), " is not size_n / 16 = ", size_n / kLayoutN);
@@ -102,11 +100,12 @@ at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(A.device());
     at::Tensor c = at::empty({size_m, activation ? size_n / 2 : size_n}, A.options());
     const int a_type = A.scalar_type() == at::kBFloat16 ? kCxxBf16 : kCxxFp16;
-    const petit_solution_hints hints{a_type, mx ? (f16_range ? kCxxMxFp4F16Range : kCxxMxFp4) : kCxxFp4, a_type, 0};
+    const petit_solution_hints hints{a_type, mx ? kCxxMxFp4 : kCxxFp4, a_type, 0};
     // ids are 64-bit patterns whose top nibble is the K split: a split of 8..15 sets bit 63, and the schema's `int` is a
     // signed int64 -- such an id arrives as its two's-complement value (petit_kernel/compiled.py maps it) and is
-    // reinterpreted here; -1 is PETIT_SOLUTION_AUTO (all ones), as in the reference (fp4.cc:189-191: solution_id < 0)
-    const uint64_t sid = (uint64_t)solution_id;
+    // reinterpreted here.  A small negative value is "library default", as in the reference (fp4.cc:189-191,240: solution_id < 0) -- including
+    // -2 / -3, which name the native class only on ITS entry point (mul_mxfp4_native): these two ops are the reference's, and exact
+    const uint64_t sid = (solution_id < 0 && solution_id >= -4096) ? PETIT_SOLUTION_AUTO : (uint64_t)solution_id;
     const petit_epilogue epi{bias.has_value() ? bias->data_ptr() : nullptr, (int32_t)activation, 0};
     // per-call scratch from the caching allocator (stream-ordered, capture-safe): K-split slabs / native-FP4 activations
     const uint64_t ws_bytes = petit_gemm_workspace_bytes_ex(&hints, (unsigned)size_m, (unsigned)size_n, (unsigned)size_k, sid,
@@ -130,11 +129,6 @@ at::Tensor mul_nvfp4_a16(const at::Tensor &A, const at::Tensor &B, const at::Ten
 at::Tensor mul_mxfp4_a16(const at::Tensor &A, const at::Tensor &B, const at::Tensor &s, const at::Tensor &gs, int64_t m, int64_t n, int64_t k,
                          int64_t solution_id, const std::optional<at::Tensor> &bias, int64_t activation) {
     return mul_a16(true, A, B, s, gs, m, n, k, solution_id, bias, activation);
-}
-// extension: the caller promises that every e8m0 scale byte lies in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h)
-at::Tensor mul_mxfp4_a16_f16range(const at::Tensor &A, const at::Tensor &B, const at::Tensor &s, const at::Tensor &gs, int64_t m, int64_t n,
-                                  int64_t k, int64_t solution_id, const std::optional<at::Tensor> &bias, int64_t activation) {
-    return mul_a16(true, A, B, s, gs, m, n, k, solution_id, bias, activation, true);
 }
 
 // Shape functions for the Meta key (FakeTensor / torch.compile tracing, torch.export): outputs of the right shape, dtype and
@@ -161,16 +155,13 @@ TORCH_LIBRARY(petit_kernel, m) {
           "Tensor? bias=None, int activation=0) -> Tensor");
     m.def("mul_mxfp4_a16(Tensor A, Tensor B, Tensor s, Tensor global_scale, int size_m, int size_n, int size_k, int solution_id, "
           "Tensor? bias=None, int activation=0) -> Tensor");
-    m.def("mul_mxfp4_a16_f16range(Tensor A, Tensor B, Tensor s, Tensor global_scale, int size_m, int size_n, int size_k, int solution_id, "
-          "Tensor? bias=None, int activation=0) -> Tensor");
 }
 #define PETIT_IMPL_REAL(m)                                      \
     m.impl("repack_nvfp4", &repack_nvfp4);                      \
     m.impl("process_nvfp4_scales", &process_nvfp4_scales);      \
     m.impl("process_mxfp4_scales", &process_mxfp4_scales);      \
     m.impl("mul_nvfp4_a16", &mul_nvfp4_a16);                    \
-    m.impl("mul_mxfp4_a16", &mul_mxfp4_a16);                    \
-    m.impl("mul_mxfp4_a16_f16range", &mul_mxfp4_a16_f16range);
+    m.impl("mul_mxfp4_a16", &mul_mxfp4_a16);
 TORCH_LIBRARY_IMPL(petit_kernel, CUDA, m) { PETIT_IMPL_REAL(m) }
 TORCH_LIBRARY_IMPL(petit_kernel, CPU, m) { PETIT_IMPL_REAL(m) }
 TORCH_LIBRARY_IMPL(petit_kernel, Meta, m) {
@@ -179,5 +170,4 @@ TORCH_LIBRARY_IMPL(petit_kernel, Meta, m) {
     m.impl("process_mxfp4_scales", &process_mxfp4_scales_meta);
     m.impl("mul_nvfp4_a16", &mul_a16_meta);
     m.impl("mul_mxfp4_a16", &mul_a16_meta);
-    m.impl("mul_mxfp4_a16_f16range", &mul_a16_meta);
 }

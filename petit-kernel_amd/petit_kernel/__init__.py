@@ -34,8 +34,8 @@ class DataType(enum.Enum):
     mxfloat4_e2m1 = 6
 
 
-# Extension, as PetitSolutionHints.b_type (a raw value of the C++ numbering; the reference's Python enum above stays as it is): MXFP4 whose every
-# e8m0 scale byte lies in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h) -- enumerates / resolves the fp16 single-MFMA family.
+# Round 3's extension value for PetitSolutionHints.b_type ("MXFP4 whose every e8m0 scale byte lies in 114..140"): still accepted, and means plain
+# MXFP4 -- the fp16 x MXFP4 kernels test the range themselves (include/petit_amd.h), there is nothing to promise any more.
 DTYPE_MXFP4_E2M1_F16RANGE = 8
 
 
@@ -53,22 +53,15 @@ def repack_mxfp4(qw: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
 
 
 def process_mxfp4_scales(scales: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
-    out = _impl.process_mxfp4_scales(scales, size_n, size_k)
-    # One look at the raw scales, at load time: do all e8m0 bytes lie in 114..140 (e2m1 x scale a normal fp16 number)?  Real checkpoints do.
-    # mul_mxfp4_a16 reads the mark off THIS tensor object and then gives fp16 activations the single-MFMA family
-    # (PETIT_DTYPE_MXFP4_E2M1_F16RANGE, include/petit_amd.h); a tensor without the mark (re-wrapped, copied, traced) takes the exact split path.
-    try:
-        if not torch.compiler.is_compiling() and scales.is_cuda:
-            out.petit_scales_in_fp16_range = mxfp4_scales_in_fp16_range(scales)
-    except Exception:  # noqa: BLE001  (fake tensors, exotic subclasses: no mark, the exact path)
-        pass
-    return out
+    # (no look at the values, no host sync, nothing attached to the tensor: the GEMM kernels decide per wave and span whether the scales they
+    # hold allow the single-MFMA fp16 body -- nn.Parameter-wrapped, copied or overwritten scale tensors all get the right kernel)
+    return _impl.process_mxfp4_scales(scales, size_n, size_k)
 
 
 def mxfp4_scales_in_fp16_range(raw_scales: torch.Tensor) -> bool:
-    """True when every e8m0 byte of the RAW (unprocessed) MXFP4 scale tensor lies in 114..140 -- the condition under which fp16 activations may
-    take the single-MFMA family (PETIT_DTYPE_MXFP4_E2M1_F16RANGE).  For pipelines that process scales offline (petit_kernel.offline) and load the
-    packed tensors later: record this bit next to them and pass it as mul_mxfp4_a16(..., scales_in_fp16_range=bit)."""
+    """A diagnostic, not an input of any call: True when every e8m0 byte of the RAW (unprocessed) MXFP4 scale tensor lies in 114..140, i.e. when
+    fp16 activations run the single-MFMA body in every wave (a wave that meets a byte outside that range finishes its K range in the exact
+    fallback body, which is slower).  Synchronises with the device."""
     if raw_scales.numel() == 0:
         return False
     lo, hi = torch.aminmax(raw_scales)
@@ -86,14 +79,9 @@ def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scal
 
 def mul_mxfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
                   size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None,
-                  activation: str = None, scales_in_fp16_range: bool = None) -> torch.Tensor:
-    # scales_in_fp16_range (extension, fp16 activations only): every e8m0 scale byte in 114..140 -- None = the mark
-    # process_mxfp4_scales left on `s` (False when there is none); True is the caller's promise, False forces the exact split path.
-    if scales_in_fp16_range is None:   # (explicit kernel ids keep the plain MXFP4 meaning they were enumerated with)
-        scales_in_fp16_range = solution_id == -1 and getattr(s, "petit_scales_in_fp16_range", False)
-    fast = bool(scales_in_fp16_range) and a.dtype == torch.float16
-    if fast:
-        return _impl.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation, True)
+                  activation: str = None) -> torch.Tensor:
+    # fp16 activations are an extension (the reference's MXFP4 path takes bf16 only, gemm_fp4_fp16_grid.cc:55-64); any negative solution_id
+    # is the library default as in the reference (fp4.cc:240) -- the native class is reached through mul_mxfp4_native only
     return _impl.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 

@@ -56,9 +56,7 @@ def _sid(solution_id: int) -> int:
     the K split in bits 60-63, so a split of 8..15 does not fit a signed int64 as such: it crosses as its two's-complement
     value and the binding reinterprets it.  Any negative id means "library default" (reference: fp4.cc:189-191)."""
     solution_id = int(solution_id)
-    if solution_id in (-2, -3):     # default pick inside the opt-in native class (ops.SOLUTION_AUTO_NATIVE_*): UINT64_MAX - 1 / - 2
-        return solution_id
-    if solution_id < 0:
+    if solution_id < 0:             # (the native class is reached through mul_mxfp4_native, never through the reference's entry points)
         return -1
     if solution_id >= 1 << 64:
         raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
@@ -81,6 +79,5 @@ def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bi
     return torch.ops.petit_kernel.mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None, f16_range=False):
-    op = torch.ops.petit_kernel.mul_mxfp4_a16_f16range if f16_range else torch.ops.petit_kernel.mul_mxfp4_a16
-    return op(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None):
+    return torch.ops.petit_kernel.mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, _sid(solution_id), bias, _act(activation))

@@ -151,11 +151,13 @@ SOLUTION_AUTO_NATIVE_MXFP8 = -2
 SOLUTION_AUTO_NATIVE_MXFP4 = -3
 
 
-def _c_solution_id(solution_id: int) -> int:
+def _c_solution_id(solution_id: int, native_ok: bool = False) -> int:
+    """Python id -> the C ABI's uint64.  Any negative id is the library default, as in the reference (fp4.cc:189,240); the native-class
+    sentinels (-2 / -3) mean themselves only where the caller has opted into that class (mul_mxfp4_native, the resolve / workspace queries)."""
     solution_id = int(solution_id)
-    if solution_id == SOLUTION_AUTO_NATIVE_MXFP8:
+    if native_ok and solution_id == SOLUTION_AUTO_NATIVE_MXFP8:
         return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8
-    if solution_id == SOLUTION_AUTO_NATIVE_MXFP4:
+    if native_ok and solution_id == SOLUTION_AUTO_NATIVE_MXFP4:
         return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4
     return _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else solution_id
 
@@ -193,7 +195,7 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
         _check(size_n % 32 == 0, f"silu_mul needs size_n % 32 == 0 (gate / up halves of whole tiles), got {size_n}")
     c = torch.empty((size_m, size_n // 2 if act else size_n), dtype=A.dtype, device=A.device)
     a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
-    b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE if kind == "mxr" else _lib.CXX_DTYPE_MXFP4_E2M1
+    b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
     # require_high_precision: the reference turns it on for arch <= gfx90a when
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
@@ -235,15 +237,14 @@ def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bi
     return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None, f16_range=False) -> torch.Tensor:
-    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue.
-    f16_range: the caller's promise that every e8m0 scale byte lies in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE)."""
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
+    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue."""
     _check(B.size(0) == size_n // _LAYOUT_N, f"B.size(0) = {B.size(0)} is not size_n / 16 = {size_n // _LAYOUT_N}")
     _check(B.size(1) == size_k * _LAYOUT_N // _PACK,
            f"B.size(1) = {B.size(1)} is not packed size = {size_k * _LAYOUT_N // _PACK}")
     _check(s.size(0) == size_n // 32, f"s.size(0) = {s.size(0)} is not size_n / 32 = {size_n // 32}")
     _check(s.size(1) == size_k, f"s.size(1) = {s.size(1)} is not size_k = {size_k}")
-    return _mul("mxr" if f16_range else "mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
+    return _mul("mx", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
 def get_fp4_solutions(*args) -> list:
@@ -291,7 +292,7 @@ def native_workspace_bytes(size_m: int, size_k: int) -> int:
 
 def workspace_bytes(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, solution_id: int = -1) -> int:
     """Scratch bytes the call would use (split-K slabs, native-FP4 activations); mul_*_a16 allocates them itself."""
-    sid = _c_solution_id(solution_id)
+    sid = _c_solution_id(solution_id, native_ok=True)
     ch = _c_hints(hints)
     return int(_lib.lib.petit_gemm_workspace_bytes(C.byref(ch), size_m, size_n, size_k, C.c_uint64(sid)))
 
@@ -303,7 +304,7 @@ def resolve_solution(hints: PetitSolutionHints, size_m: int, size_n: int, size_k
     ch = _c_hints(hints)
     act = _ACTIVATIONS[activation]
     epi = _lib.Epilogue(None, act, 0)
-    return int(_lib.lib.petit_gemm_resolve_solution(C.byref(ch), size_m, size_n, size_k, C.c_uint64(_c_solution_id(solution_id)),
+    return int(_lib.lib.petit_gemm_resolve_solution(C.byref(ch), size_m, size_n, size_k, C.c_uint64(_c_solution_id(solution_id, native_ok=True)),
                                                     C.byref(epi) if act else None, C.c_uint64(workspace_bytes)))
 
 
@@ -403,7 +404,7 @@ def mul_mxfp4_native(A, B, s, global_scale, size_m, size_n, size_k, solution_id=
     _check(not out_fmt or act, "out_quantized needs activation='silu_mul'")
     a_type = _lib.CXX_DTYPE_BF16 if dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
     hints = _CHints(a_type, _lib.CXX_DTYPE_MXFP4_E2M1, a_type, 0)
-    sid = _c_solution_id(solution_id)
+    sid = _c_solution_id(solution_id, native_ok=True)
     epi = None
     if bias is not None or act:
         if bias is not None:
@@ -457,11 +458,6 @@ def mul_fp4_a16_grouped(kind: str, A: torch.Tensor, members, size_m: int, size_k
         arr[i] = _lib.GroupMember(c.data_ptr(), B.data_ptr(), s.data_ptr(), gs.data_ptr(), bias.data_ptr() if bias is not None else None, n, 0)
     a_type = _lib.CXX_DTYPE_BF16 if A.dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
     b_type = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1
-    # fp16 activations, default pick, EVERY member's scales marked by process_mxfp4_scales as lying in fp16's range: the single-MFMA family
-    # (PETIT_DTYPE_MXFP4_E2M1_F16RANGE), as mul_mxfp4_a16 does for one matrix
-    if kind == "mxfp4" and A.dtype == torch.float16 and int(solution_id) == -1 and \
-            all(getattr(mem[1], "petit_scales_in_fp16_range", False) for mem in members):
-        b_type = _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE
     hints = _CHints(a_type, b_type, a_type, 0)
     with torch.cuda.device(A.device):
         err = _lib.lib.petit_gemm_fp4_fp16_grouped(arr, len(members), _ptr(A), size_m, size_k, C.byref(hints), C.c_uint64(_c_solution_id(solution_id)),

@@ -25,7 +25,7 @@ _KLASS = {"exact": 0, "native_mxfp8": 8, "native_mxfp4": 4}
 
 def _hints(dtype, kind: str) -> _lib.SolutionHints:
     a = _lib.CXX_DTYPE_BF16 if dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
-    b = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE if kind == "mxfp4_f16range" else _lib.CXX_DTYPE_MXFP4_E2M1
+    b = _lib.CXX_DTYPE_FP4_E2M1 if kind == "nvfp4" else _lib.CXX_DTYPE_MXFP4_E2M1
     return _lib.SolutionHints(a, b, a, 0)
 
 
@@ -35,7 +35,7 @@ def tune_tensors(A: torch.Tensor, packed, global_scale: torch.Tensor, size_m: in
     pairs to rotate over; with a single pair the library clones it on the device up to `rotate_mb`.
     Returns (solution_id, microseconds per launch); with persist=True `solution_id = -1` picks it from now on."""
     if kind not in ("nvfp4", "mxfp4", "mxfp4_f16range") or klass not in _KLASS:
-        raise RuntimeError("kind must be 'nvfp4', 'mxfp4' or 'mxfp4_f16range' (fp16 activations, every e8m0 scale in 114..140), klass one of " + ", ".join(_KLASS))
+        raise RuntimeError("kind must be 'nvfp4' or 'mxfp4' ('mxfp4_f16range', round 3's name for fp16-safe scales, still reads as 'mxfp4'), klass one of " + ", ".join(_KLASS))
     if A.dtype not in (torch.bfloat16, torch.float16) or not A.is_cuda or not A.is_contiguous() or A.numel() != size_m * size_k:
         raise RuntimeError("A must be a contiguous [size_m, size_k] bfloat16 / float16 GPU tensor")
     pairs = [packed] if isinstance(packed[0], torch.Tensor) else list(packed)

@@ -69,9 +69,7 @@ def check_gemm(c_bits, ref_f32, is_bf16, sum_abs=None, sum_abs_coef=1e-5):
     assert np.median(rel) < (2 ** -8 if is_bf16 else 2 ** -11)
 
 
-def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1, mx_f16_range=None):
-    """mx_f16_range (MXFP4 only): None = what a caller gets (process_mxfp4_scales marks scales that lie in 114..140 and fp16 activations then take
-    the single-MFMA family under solution_id = -1), False = force the exact hi / lo split family, True = the caller's promise."""
+def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1):
     dtype = torch.bfloat16 if is_bf16 else torch.float16
     a = from_bits(a_bits, dtype).to(DEV)
     qd = torch.from_numpy(q).to(DEV)
@@ -83,7 +81,7 @@ def run_case(pk, kind, a_bits, is_bf16, q, s, gs, m, n, k, solution_id=-1, mx_f1
     else:
         b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
         sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
-        c = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, solution_id, scales_in_fp16_range=mx_f16_range)
+        c = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, solution_id)
     torch.cuda.synchronize()
     assert c.shape == (m, n) and c.dtype == dtype and c.is_cuda
     return bits(c)
@@ -277,61 +275,101 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     a, q, s, gs = random_problem(kind, m, n, k, 1000 + m + n + k, is_bf16)
     c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k)
     check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
-    if kind == "mx" and not is_bf16:   # the call above took the fp16-range family (scales 119..135 are marked); the exact split family too
-        c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, mx_f16_range=False)
-        check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
-MX_F16RANGE_PROBLEMS = [(1, 256, 2048), (3, 96, 512), (8, 160, 1024), (16, 288, 1024), (40, 64, 3072), (64, 128, 2048), (130, 256, 1024), (300, 512, 768),
-                        (2, 4128, 4096), (512, 1024, 2048)]
+MX_F16_PROBLEMS = [(1, 256, 2048), (3, 96, 512), (8, 160, 1024), (16, 288, 1024), (40, 64, 3072), (64, 128, 2048), (130, 256, 1024), (300, 512, 768),
+                   (2, 4128, 4096), (512, 1024, 2048), (16, 512, 8192), (256, 256, 4096)]
 
 
-@pytest.mark.parametrize("m,n,k", MX_F16RANGE_PROBLEMS)
-def test_fp16_mxfp4_f16range_every_solution(pk, m, n, k):
-    """fp16 x MXFP4 with every e8m0 scale in 114..140 (PETIT_DTYPE_MXFP4_E2M1_F16RANGE): weights convert straight to fp16, one MFMA per
-    fragment, every kernel family.  Scales drawn over the WHOLE promised range, both ends included; every enumerated kernel and the default
-    pick against the oracle, and the default pick against the exact split family on the same inputs."""
-    a, q, s, gs = random_problem("mx", m, n, k, 4242 + m + n + k, False, mx_band=(114, 141))
-    s[0, 0], s[-1, -1] = 114, 140
-    ref = oracle_ref("mx", a, False, q, s, gs)
-    sum_abs = oracle_sum_abs("mx", a, False, q, s, gs)
+def mx_f16_scale_profiles(n, k, seed):
+    """MXFP4 scale tensors that drive the fp16 x MXFP4 kernels (Fp16Mx, csrc/device_common.hpp) through each of their bodies, with the global
+    scale that brings the outputs to O(1) (the parity bound has an absolute floor of 1e-2: tiny outputs would pass vacuously):
+      fast      every byte in 114..140, both ends present: the single-MFMA fp16 body everywhere
+      fallback  every byte in 96..113: the exact bf16 hi / lo body from the first span on
+      switch    in range, with a sprinkle of bytes just outside it (100..113, 141..143) placed in the SECOND half of K for the even 16-row
+                tiles and anywhere for a few others: waves start in the fast body and switch at different spans, neighbours never do"""
+    rng = np.random.default_rng(seed)
+    kb = k // 32
+    fast = rng.integers(114, 141, (n, kb), dtype=np.uint8)
+    fast[0, 0], fast[-1, -1] = 114, 140
+    fallback = rng.integers(96, 114, (n, kb), dtype=np.uint8)
+    switch = rng.integers(128, 141, (n, kb), dtype=np.uint8)
+    for t in range(0, n // 16, 2):          # even tiles: one odd byte somewhere in the second half of K
+        switch[16 * t + rng.integers(0, 16), kb // 2 + rng.integers(0, max(1, kb - kb // 2))] = rng.choice([100, 113, 141, 143])
+    for t in rng.integers(0, n // 16, max(1, n // 64)):   # a few tiles: odd bytes anywhere (incl. the very first block)
+        switch[16 * t + rng.integers(0, 16), rng.integers(0, kb)] = rng.choice([112, 142])
+    switch[5 % n, 0] = 141
+    return {"fast": (fast, 2.0 ** -12), "fallback": (fallback, 2.0 ** 13), "switch": (switch, 2.0 ** -13)}
+
+
+@pytest.mark.parametrize("m,n,k", MX_F16_PROBLEMS)
+def test_fp16_mxfp4_every_solution_fast_fallback_switch(pk, m, n, k):
+    """fp16 x MXFP4 decides in the kernel, per wave and span, between the single-MFMA fp16 body (scale bytes 114..140) and the exact fallback
+    for any e8m0 scale -- no caller promise, no tensor mark.  Every enumerated kernel and the default pick against the oracle on scale
+    profiles that keep every wave in the fast body, put every wave in the fallback, and make waves switch at different spans."""
+    a, q, _, _ = random_problem("mx", m, n, k, 4242 + m + n + k, False)
     h = pk.PetitSolutionHints()
     h.a_type = h.c_type = torch.float16
-    h.b_type = pk.DTYPE_MXFP4_E2M1_F16RANGE
+    h.b_type = pk.DataType.mxfloat4_e2m1
     sols = pk.ops.get_fp4_solutions(h, m, n, k)
-    plain = pk.PetitSolutionHints()
-    plain.a_type = plain.c_type = torch.float16
-    plain.b_type = pk.DataType.mxfloat4_e2m1
-    assert sols and not set(sols) & set(pk.ops.get_fp4_solutions(plain, m, n, k))   # ids carry their own element nibble
-    for sid in [-1] + list(sols):
-        check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k, sid, mx_f16_range=True), ref, False, sum_abs)
-    # what an unchanged call site gets: the mark -> the same family under solution_id = -1 (bit-identical to the explicit promise)
-    auto = run_case(pk, "mx", a, False, q, s, gs, m, n, k)
-    assert np.array_equal(auto, run_case(pk, "mx", a, False, q, s, gs, m, n, k, mx_f16_range=True))
-    assert (pk.ops.resolve_solution(h, m, n, k) & ~(0xF << 60)) | (1 << 60) in sols   # (the pick may carry a K split)
+    assert sols and all((sid >> 28) & 0xF == 2 for sid in sols)
+    assert any((sid >> 48) & 0xF == 12 for sid in sols) or k % 1024 or m < 1      # the 32x32x16 kernels exist for this family now
+    for name, (s, gs) in mx_f16_scale_profiles(n, k, 77 + n + k).items():
+        ref = oracle_ref("mx", a, False, q, s, gs)
+        sum_abs = oracle_sum_abs("mx", a, False, q, s, gs)
+        assert np.isfinite(ref).all() and np.abs(ref).max() > 0.05, name   # the check below is not vacuous
+        for sid in [-1] + list(sols):
+            try:
+                check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k, sid), ref, False, sum_abs)
+            except AssertionError as e:
+                raise AssertionError(f"profile {name}, solution {sid:#x}: {e}") from None
+        for splitk in (2, 4):   # K splits across workgroups: the slices start in different spans
+            for sid in sols:
+                if (sid >> 48) & 0xF in (0, 8, 12) and k // (128 * (8 if k % 1024 == 0 else 4 if k % 512 == 0 else 2)) >= splitk:
+                    sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                    try:
+                        check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k, sk), ref, False, sum_abs)
+                    except AssertionError as e:
+                        raise AssertionError(f"profile {name}, solution {sk:#x}: {e}") from None
+                    break
 
 
-def test_fp16_mxfp4_f16range_mark(pk):
-    """process_mxfp4_scales marks in-range scales and only those; out-of-range scales keep the exact split family (and stay correct)."""
-    m, n, k = 5, 128, 1024
-    for band, expect in (((114, 141), True), ((113, 141), False), ((114, 142), False), ((0, 255), False)):
-        a, q, s, gs = random_problem("mx", m, n, k, 99, False, mx_band=band)
-        s[0, 0], s[-1, -1] = band[0], band[1] - 1
-        sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
-        assert getattr(sp, "petit_scales_in_fp16_range", None) is expect
-        if band != (0, 255):   # (the full range overflows fp16 outputs: covered by test_mx_extreme_scales-style cases below)
-            check_gemm(run_case(pk, "mx", a, False, q, s, gs, m, n, k), oracle_ref("mx", a, False, q, s, gs), False,
-                       oracle_sum_abs("mx", a, False, q, s, gs))
-    # the in-library tuner ranks the family's own kernels
-    a, q, s, gs = random_problem("mx", m, n, k, 101, False, mx_band=(114, 141))
+def test_fp16_mxfp4_no_promise_no_mark(pk):
+    """What round 3 got wrong, pinned: nothing about the fast path hangs on the Python tensor object.  nn.Parameter-wrapped scales, a clone,
+    and a scale tensor OVERWRITTEN IN PLACE with out-of-range values all give the oracle's result; the deprecated b_type 8 and the tuner's
+    old kind name are plain MXFP4; process_mxfp4_scales attaches nothing and does not look at the values."""
+    m, n, k = 16, 256, 4096
+    a, q, s_in, _ = random_problem("mx", m, n, k, 99, False, mx_band=(118, 137))
+    gs = 2.0 ** -6
+    ad = from_bits(a, torch.float16).to(DEV)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
     b = pk.repack_mxfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
-    sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
-    sid, us = pk.tune_tensors(from_bits(a, torch.float16).to(DEV), (b, sp), torch.tensor([gs], dtype=torch.float32, device=DEV), m, n, k,
-                              kind="mxfp4_f16range", persist=False, rotate_mb=16)
-    assert (sid >> 28) & 0xF == 3 and us > 0
-    # bf16 activations ignore the mark and the promise
-    a, q, s, gs = random_problem("mx", m, n, k, 100, True, mx_band=(114, 141))
-    assert np.array_equal(run_case(pk, "mx", a, True, q, s, gs, m, n, k), run_case(pk, "mx", a, True, q, s, gs, m, n, k, mx_f16_range=True))
+    sp = pk.process_mxfp4_scales(torch.from_numpy(s_in).to(DEV), n, k)
+    assert not hasattr(sp, "petit_scales_in_fp16_range")
+    ref_in = oracle_ref("mx", a, False, q, s_in, gs)
+    c0 = pk.mul_mxfp4_a16(ad, b, sp, gsd, m, n, k, -1)
+    check_gemm(bits(c0), ref_in, False, oracle_sum_abs("mx", a, False, q, s_in, gs))
+    for alias in (torch.nn.Parameter(sp, requires_grad=False), sp.clone(), sp.data):
+        assert torch.equal(pk.mul_mxfp4_a16(ad, b, alias, gsd, m, n, k, -1), c0)
+    # weight hot-swap into the SAME tensor object: scales far outside fp16's range (2^-37 .. 2^-17), outputs brought back by the global scale
+    s_out = np.random.default_rng(5).integers(90, 111, (n, k // 32), dtype=np.uint8)
+    sp.copy_(pk.process_mxfp4_scales(torch.from_numpy(s_out).to(DEV), n, k))
+    gs2 = 2.0 ** 22
+    ref_out = oracle_ref("mx", a, False, q, s_out, gs2)
+    assert np.abs(ref_out).max() > 0.05
+    c1 = pk.mul_mxfp4_a16(ad, b, sp, torch.tensor([gs2], dtype=torch.float32, device=DEV), m, n, k, -1)
+    check_gemm(bits(c1), ref_out, False, oracle_sum_abs("mx", a, False, q, s_out, gs2))
+    # the deprecated dtype value is an alias at the C ABI (hints.b_type = 8) ...
+    h7, h8 = pk.PetitSolutionHints(), pk.PetitSolutionHints()
+    for h, bt in ((h7, pk.DataType.mxfloat4_e2m1), (h8, pk.DTYPE_MXFP4_E2M1_F16RANGE)):
+        h.a_type = h.c_type = torch.float16
+        h.b_type = bt
+    assert pk.ops.get_fp4_solutions(h7, m, n, k) == pk.ops.get_fp4_solutions(h8, m, n, k)
+    assert pk.ops.resolve_solution(h7, m, n, k) == pk.ops.resolve_solution(h8, m, n, k) != 0
+    # ... and so is the tuner's old kind name
+    sid, us = pk.tune_tensors(ad, (b, sp), gsd, m, n, k, kind="mxfp4_f16range", persist=False, rotate_mb=16)
+    assert (sid >> 28) & 0xF == 2 and us > 0
+    assert pk.mxfp4_scales_in_fp16_range(torch.from_numpy(s_in).to(DEV)) and not pk.mxfp4_scales_in_fp16_range(torch.from_numpy(s_out).to(DEV))
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 256, 2048), (16, 272, 1024), (40, 64, 3072), (9, 96, 512), (2, 32, 256), (7, 96, 2048),
@@ -650,12 +688,9 @@ def test_compiled_and_ctypes_bindings_agree(pk):
             assert c1.shape == c2.shape and torch.equal(c1.view(torch.int16), c2.view(torch.int16)), (kind, sid, kw)
         check_gemm(bits(mul1(ad, b1, s1, gsd, m, n, k, -1)), oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16,
                    oracle_sum_abs(kind, a, is_bf16, q, s, gs))
-        if kind == "mx" and not is_bf16:   # the fp16-range family (extension op / b_type) through both layers
-            for kw in ({}, {"bias": bias}, {"activation": "silu_mul"}):
-                c1, c2 = mul1(ad, b1, s1, gsd, m, n, k, -1, f16_range=True, **kw), mul2(ad, b1, s1, gsd, m, n, k, -1, f16_range=True, **kw)
-                assert c1.shape == c2.shape and torch.equal(c1.view(torch.int16), c2.view(torch.int16)), ("mx f16 range", kw)
-            check_gemm(bits(mul1(ad, b1, s1, gsd, m, n, k, -1, f16_range=True)), oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16,
-                       oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+        for neg in (-2, -3, -7):   # any negative id is the library default on the reference's entry points (fp4.cc:189,240), through both layers
+            assert torch.equal(mul1(ad, b1, s1, gsd, m, n, k, neg).view(torch.int16), mul1(ad, b1, s1, gsd, m, n, k, -1).view(torch.int16))
+            assert torch.equal(mul2(ad, b1, s1, gsd, m, n, k, neg).view(torch.int16), mul2(ad, b1, s1, gsd, m, n, k, -1).view(torch.int16))
 
 
 def test_compiled_ops_trace_without_graph_break(pk):
@@ -1005,10 +1040,7 @@ class FullSizeProblem:
         else:
             self.b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
             self.sp = pk.process_mxfp4_scales(torch.from_numpy(self.s).to(DEV), n, k)
-            # mx_f16_range: None = what a caller gets (the scales, 119..135, are marked: fp16 activations take the single-MFMA family under -1),
-            # False = force the exact hi / lo split family
-            self.mx_f16_range = None
-            self.mul = lambda *args, **kw: pk.mul_mxfp4_a16(*args, scales_in_fp16_range=self.mx_f16_range, **kw)
+            self.mul = pk.mul_mxfp4_a16
         del qd
         self.gs = 0.75
         self.gsd = torch.tensor([self.gs], dtype=torch.float32, device=DEV)
@@ -1031,7 +1063,9 @@ class FullSizeProblem:
     def run(self, a_bits, is_bf16, sid=-1):
         dtype = torch.bfloat16 if is_bf16 else torch.float16
         m = a_bits.shape[0]
-        c = self.mul(from_bits(a_bits, dtype).to(DEV), self.b, self.sp, self.gsd, m, self.n, self.k, sid)
+        # (the native-class sentinels name that class on its own entry point only; the reference's entry points read any negative id as -1)
+        mul = self.pk.mul_mxfp4_native if sid in (self.pk.SOLUTION_AUTO_NATIVE_MXFP8, self.pk.SOLUTION_AUTO_NATIVE_MXFP4) else self.mul
+        c = mul(from_bits(a_bits, dtype).to(DEV), self.b, self.sp, self.gsd, m, self.n, self.k, sid)
         torch.cuda.synchronize()
         return c
 
@@ -1168,13 +1202,14 @@ def test_bench_cells_parity(pk):
     assert [c["mode"] for c in full_plan if c["shape"] == "mlp"] == ["mlp_" + m_ for m_ in BL.MlpBlock.MODES]   # -> test_bench_mlp_block_cells
     assert {c["mode"] for c in full_plan if c["shape"].startswith("tp8")} == {"separate", "grouped"}            # -> test_grouped_launch
     plan = [c for c in full_plan if c["mode"] != "hipblaslt" and c["shape"] in BL.LLAMA70B]
-    assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx"), ("fp16", "mxr")}
+    assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx")}
+    assert {c["M"] for c in plan if (c["a"], c["w"], c["mode"]) == ("bf16", "mx", "auto")} == {1, 16, 512}   # the reference's only MX activation type
     assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512}          # configs[1..2] + M = 512
     ran = 0
     for shape in BL.SHAPE_ORDER:
         n, k = BL.LLAMA70B[shape]
         for w in ("nv", "mx"):
-            cells = [c for c in plan if c["shape"] == shape and c["w"] in ((w, "mxr") if w == "mx" else (w,))]
+            cells = [c for c in plan if c["shape"] == shape and c["w"] == w]
             if not cells:
                 continue
             P = FullSizeProblem(pk, w, n, k, 7 * n + k + len(w))
@@ -1182,16 +1217,9 @@ def test_bench_cells_parity(pk):
                 m, is_bf16, mode = c["M"], c["a"] == "bf16", c["mode"]
                 a = P.activations(m, is_bf16, 900 + m)
                 tag = f"{shape} M={m} {c['a']}x{c['w']} {mode}"
-                if w == "mx":   # bench.py times "mx" with plain MXFP4 hints (fp16: the split family) and "mxr" with the fp16-range promise
-                    P.mx_f16_range = None if c["w"] == "mxr" else False
                 if mode == "auto":
-                    hints = P.hints(is_bf16)
-                    if c["w"] == "mxr":
-                        assert P.sp.petit_scales_in_fp16_range is True and not is_bf16
-                        hints.b_type = pk.DTYPE_MXFP4_E2M1_F16RANGE
-                    picked = pk.ops.resolve_solution(hints, m, n, k, -1)
+                    picked = pk.ops.resolve_solution(P.hints(is_bf16), m, n, k, -1)
                     assert picked and (picked >> 48) & 0xF not in (9, 13), tag
-                    assert ((picked >> 28) & 0xF == 3) == (c["w"] == "mxr"), tag
                     P.check_properties(m, is_bf16)
                     P.check_sampled(P.run(a, is_bf16), a, is_bf16, f"{tag} -> {picked:#x}")
                 else:

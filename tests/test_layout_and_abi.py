@@ -123,9 +123,9 @@ def test_solution_enumeration_and_ids():
     assert auto in sols
 
 
-def test_mxfp4_f16range_family_enumerates_without_a_gpu():
-    """The fp16-range MXFP4 extension type (include/petit_amd.h): header value = Python value; with fp16 activations it names a family of its own
-    (element nibble 3, disjoint ids, describe says so), with bf16 activations it is plain MXFP4; NVFP4 entry points do not know it."""
+def test_mxfp4_f16range_dtype_is_an_alias_without_a_gpu():
+    """PETIT_DTYPE_MXFP4_E2M1_F16RANGE (round 3: a caller's promise that selected a kernel family) is a deprecated alias of plain MXFP4: the fp16
+    kernels test the scale range themselves.  Header value = Python value; same ids, same default, the full kernel set for fp16 activations."""
     import re
     from petit_kernel import _lib
     hdr = (ROOT / "include" / "petit_amd.h").read_text()
@@ -142,14 +142,17 @@ def test_mxfp4_f16range_family_enumerates_without_a_gpu():
         buf = (C.c_uint64 * max(cnt.value, 1))()
         assert _lib.lib.petit_gemm_get_solutions(C.byref(h), m, n, k, buf, C.byref(cnt)) == 0
         return [int(buf[i]) for i in range(cnt.value)]
-    fast, split = ids(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE), ids(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1)
-    assert fast and all((i >> 28) & 0xF == 3 for i in fast) and all((i >> 28) & 0xF == 2 for i in split) and not set(fast) & set(split)
-    assert any((i >> 36) & 0xF == 2 and (i >> 48) & 0xF in (10, 11) for i in fast)   # the shared-tile kernel: not available to the split family
-    assert not any((i >> 36) & 0xF == 2 and (i >> 48) & 0xF in (10, 11) for i in split)
-    assert "f16-range" in _lib.describe_solution(fast[0]) and "f16-range" not in _lib.describe_solution(split[0])
-    assert ids(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE) == ids(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1)
-    dflt = _lib.lib.petit_gemm_default_solution(C.byref(_lib.SolutionHints(4, 8, 4, 0)), 16, 8192, 8192)
-    assert (dflt & ~(0xF << 60)) | (1 << 60) in fast
+    for a in (_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_BF16):
+        plain, alias = ids(a, _lib.CXX_DTYPE_MXFP4_E2M1), ids(a, _lib.CXX_DTYPE_MXFP4_E2M1_F16RANGE)
+        assert plain and plain == alias and all((i >> 28) & 0xF == 2 for i in plain)
+    f16 = ids(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1)
+    assert any((i >> 36) & 0xF == 2 and (i >> 48) & 0xF in (10, 11) for i in f16)   # the shared-tile kernel
+    assert any((i >> 48) & 0xF == 12 for i in ids(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1, m=512))   # the 32x32x16 kernels
+    dflt = [_lib.lib.petit_gemm_default_solution(C.byref(_lib.SolutionHints(4, b, 4, 0)), 16, 8192, 8192) for b in (7, 8)]
+    assert dflt[0] == dflt[1] and (dflt[0] & ~(0xF << 60)) | (1 << 60) in f16
+    # an id written with round 3's element nibble (3) still names its kernel
+    old = (f16[0] & ~(0xF << 28)) | (3 << 28)
+    assert _lib.describe_solution(old) == _lib.describe_solution(f16[0])
 
 
 def test_error_codes_without_a_gpu():

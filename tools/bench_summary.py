@@ -11,13 +11,13 @@ print(f"Headline (BASELINE configs[1], M = 1, N = K = 8192, bf16 x NVFP4, soluti
       f"{d['roofline']['frac']:.3f} of 8 TB/s** ({d['steps']} graph-replayed steps x {d['config'].get('timed_regions', 1)} regions, median)"
       + (f"; as the driver runs it ({d20['steps']} steps): {d20['ms_per_step'] * 1e3:.2f} us = {d20['roofline']['frac']:.3f}." if d20 else "."))
 print("\nHBM-bound cells (us per call, fraction of 8 TB/s):\n")
-cols = [("bf16xnv", 1), ("bf16xnv", 4), ("bf16xnv", 8), ("bf16xnv", 16), ("fp16xnv", 16), ("fp16xmx", 1), ("fp16xmx", 16), ("fp16xmxr", 1), ("fp16xmxr", 16)]
+cols = [("bf16xnv", 1), ("bf16xnv", 4), ("bf16xnv", 8), ("bf16xnv", 16), ("fp16xnv", 16), ("fp16xmx", 1), ("fp16xmx", 16), ("bf16xmx", 1), ("bf16xmx", 16)]
 print("| shape | " + " | ".join(f"{dt} M={m}" for dt, m in cols) + " |")
 print("|---|" + "---|" * len(cols))
 for s in shapes:
     print(f"| {s} | " + " | ".join(f"{cells[(s, m, dt)]['us']:.2f} us, {cells[(s, m, dt)]['frac']:.2f}" if (s, m, dt) in cells else "-" for dt, m in cols) + " |")
 print("\nM = 512 (TFLOP/s; fraction of 2.5 PF bf16 peak, native: of the 5 / 10 PF FP8 / FP4 peaks; native cells include the activation-quantiser launch):\n")
-cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("fp16xmxr", "fp16 x MXFP4, scales in fp16 range"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"),
+cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("fp16xmx", "fp16 x MXFP4"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"),
         ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xdense hipblaslt", "hipBLASLt bf16 dense")]
 print("| shape | " + " | ".join(name for _, name in cols) + " |")
 print("|---|" + "---|" * len(cols))

@@ -46,7 +46,7 @@ def main():
                 dflt = g.resolve(_lib.PETIT_SOLUTION_AUTO)
                 t_d1 = g.time(dflt, stream, reps=5)["us"]
                 with torch.cuda.stream(stream):
-                    tuned, _ = pk.tune_tensors(g.a, w.packed, g.gs, m, n, k, {"nv": "nvfp4", "mx": "mxfp4", "mxr": "mxfp4_f16range"}[fmt], persist=False)
+                    tuned, _ = pk.tune_tensors(g.a, w.packed, g.gs, m, n, k, {"nv": "nvfp4", "mx": "mxfp4"}[fmt], persist=False)
                 rec = {"family": fam, "n": n, "k": k, "m": m, "default": f"0x{dflt:x}", "default_us": t_d1, "tuned": f"0x{tuned:x}"}
                 if tuned != dflt:
                     t_t = g.time(tuned, stream, reps=5)["us"]

@@ -41,7 +41,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="sq8192,sq4096,qkv,gate_up,down")
     ap.add_argument("--ms", default="1,4,8,16")
-    ap.add_argument("--fmt", default="nv", choices=["nv", "mx", "mxr"], help="mxr: MXFP4 with scales promised in the fp16-safe range (fp16 activations)")
+    ap.add_argument("--fmt", default="nv", choices=["nv", "mx"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--splitk", default="1", help="comma list of split-K factors to try on top of each shape")
     ap.add_argument("--splitk-kinds", default="all", choices=["all", "tiled", "stream"],
