@@ -169,6 +169,22 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
+// hipcc (ROCm 7.2, gfx950) can miss the "MFMA writes VGPRs -> VALU reads them" hazard when the reader sits in a different basic block than the
+// last MFMA: at the join after the Fp16Mx fast / fallback branch it issued v_pk_add_f32 two instructions after the v_mfma that writes its
+// operand (found on hardware: the .zw half of every accumulator pair lost).  Wherever accumulators cross such a join:
+// mfma_join_pin(acc) on every accumulator, mfma_join_settle() once, mfma_join_pin(acc) again -- the pins are empty asm statements that order
+// the wait after the MFMAs and before the readers, the settle is 32 wait states (the longest MFMA here takes 16 passes).
+template <class V> __device__ __forceinline__ void mfma_join_pin(V &acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(acc));
+#endif
+}
+__device__ __forceinline__ void mfma_join_settle() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+
 // Fp16Mx fallback: one weight word (bf16, any scale) against an fp16 activation fragment already split into hi + lo.
 __device__ __forceinline__ f32x4 mfma16_hilo(bf16x8 w, const u32x4 &hi, const u32x4 &lo, f32x4 c) {
     c = mfma16(w, __builtin_bit_cast(bf16x8, hi), c);

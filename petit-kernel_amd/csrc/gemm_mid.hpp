@@ -271,6 +271,16 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_mid_kernel(const void *arg
                     __builtin_amdgcn_s_barrier();
                 }
             }
+            // the join of the two bodies: see mfma_join_settle (device_common.hpp)
+            static_for<0, 2>([&](auto pass) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < NACC; ++q)
+                        mfma_join_pin(acc[nt][q]);
+                if constexpr (decltype(pass)::value == 0)
+                    mfma_join_settle();
+            });
         } else {
             for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
                 span_body(sp, std::false_type{});

@@ -524,6 +524,18 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                 span_body(sp_end - 1, std::true_type{}, std::false_type{});
             else
                 mx_fallback(sp);
+            // the join of the two bodies: see mfma_join_settle (device_common.hpp)
+            static_for<0, 2>([&](auto pass) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < NACC; ++q)
+                            mfma_join_pin(acc[mt][nt][q]);
+                if constexpr (decltype(pass)::value == 0)
+                    mfma_join_settle();
+            });
         } else if constexpr (AT::kBfp) {
             // exact block-floating-point spans first; from the first span that fails the range check (its flag is set
             // by the write_a_stage that put it in LDS: the prologue's, or the previous span's) the bf16 pipeline

@@ -268,6 +268,16 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_til
                     __syncthreads();
             }
         }
+        // the join of the two bodies: see mfma_join_settle (device_common.hpp)
+        static_for<0, 2>([&](auto pass) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    mfma_join_pin(acc[mt][nt]);
+            if constexpr (decltype(pass)::value == 0)
+                mfma_join_settle();
+        });
     } else {
         for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
             span_body(sp, std::false_type{});

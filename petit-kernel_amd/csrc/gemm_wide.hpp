@@ -445,6 +445,17 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
         span_body(sp, std::false_type{});
     span_body(sp_end - 1, std::true_type{});
     } // (fast body)
+    if constexpr (AT::kAdaptive) { // the join of the two bodies: see mfma_join_settle (device_common.hpp)
+        static_for<0, 2>([&](auto pass) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int np = 0; np < NP; ++np)
+                    mfma_join_pin(acc[mb][np]);
+            if constexpr (decltype(pass)::value == 0)
+                mfma_join_settle();
+        });
+    }
 
     if constexpr (KG == 2) {
         // a group with fewer spans than its partner keeps the partner's barrier count (a span is KS barriers: the prologue's stands in for
