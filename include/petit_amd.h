@@ -359,11 +359,16 @@ int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned coun
  * winner becomes what PETIT_SOLUTION_AUTO (klass 0) or PETIT_SOLUTION_AUTO_NATIVE_* (klass 8 / 4) picks for (dtypes, n, k)
  * and the M bucket of m (or [m_lo, m_hi] when given) from now on, in this process; petit_tune_save() writes all such rows in
  * the $PETIT_AMD_TUNE_FILE format, which a later process loads on its first call.  `c` is scratch output (overwritten).
- * The call synchronises `stream`, allocates device memory and must not run inside a graph capture
- * (PETIT_ERROR_BAD_ARGUMENT).  Returns PETIT_ERROR_KERNEL_SHAPE when no candidate passed.
+ * The call synchronises `stream`, allocates device memory (from the pool of petit_tune_reserve when there is one, else with hipMalloc)
+ * and must not run inside a graph capture (PETIT_ERROR_BAD_ARGUMENT).  Returns PETIT_ERROR_KERNEL_SHAPE when no candidate passed.
  * $PETIT_AMD_AUTOTUNE=1 does the same implicitly: the first PETIT_SOLUTION_AUTO call of a (dtypes, n, k, M bucket) that no table
- * knows is tuned in place (own scratch, own clones of the caller's weights) before it runs, and $PETIT_AMD_TUNE_FILE, when
- * set, is rewritten with the new row.
+ * knows is tuned in place before it runs -- once per key and process, with the scratch of THAT call (so the winner is a kernel this
+ * caller can run) and device memory from the pool of petit_tune_reserve (else hipMalloc).  Every tuning run exchanges the calling
+ * thread's stream-capture mode to hipStreamCaptureModeRelaxed for its duration: measured on ROCm 7.2 (tools/probes/capture_legal.hip),
+ * that is what lets it synchronise its own stream and allocate while a capture is in progress on ANOTHER stream of the process (global
+ * capture mode: torch.cuda.graph) without invalidating that capture; a capture on the tuning stream itself is refused as above.  When
+ * $PETIT_AMD_TUNE_FILE is set the new row is merged into that file (rows other processes saved meanwhile are kept; the file is
+ * replaced by rename(), under an advisory lock on "<file>.lock").
  */
 typedef struct petit_tune_params {
     uint32_t struct_bytes;       /* sizeof(petit_tune_params) */
@@ -383,6 +388,13 @@ typedef struct petit_tune_params {
 int petit_gemm_tune(unsigned *c, const unsigned *a, const float *global_scale, unsigned m, unsigned n, unsigned k,
                     const petit_solution_hints *hints, const petit_tune_params *params, void *workspace, uint64_t workspace_bytes,
                     void *stream, uint64_t *best_solution, float *best_us);
+/* Hand the tuner a block of device memory (256-byte aligned; the caller keeps ownership and must keep it alive until it reserves
+ * another block or nullptr) for the current device: the reference output, result words and the clones of the caller's weights that a
+ * tuning run rotates over come out of it.  Sized for the largest problem to be tuned: M*N*2 bytes + as many (weights + scales) copies
+ * as fit, ideally > 256 MB of them (fewer copies = timings that see the Infinity Cache; the ranking still holds); what does not fit is
+ * allocated with hipMalloc for the run.  Optional: it spares a serving process the allocation of a few hundred MB inside a GEMM call, and
+ * it is what makes tuning possible when the process's own allocator already holds the whole device. */
+int petit_tune_reserve(void *device_ptr, uint64_t bytes);
 /* Add one row by hand (e.g. from a sweep done elsewhere): solution must be a kernel id of this build. */
 int petit_tune_insert(const petit_solution_hints *hints, unsigned n, unsigned k, unsigned m_lo, unsigned m_hi, uint64_t solution);
 /* Write the run-time rows and the rows loaded from $PETIT_AMD_TUNE_FILE to `path` (same format). */

@@ -575,8 +575,18 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     unsigned splitk = 1;
     if (is_auto) {
         // $PETIT_AMD_AUTOTUNE=1: a problem no table knows is tuned once, here, before its first real launch (tune.hip)
-        if (klass == kClassExact && !act && autotune_enabled() && tuned_solution(dev, hints->a_type, b_type, m, n, k, kClassExact) == 0)
-            autotune_on_first_sight(b_type, c, a, b, scales, global_scale, m, n, k, hints->a_type, stream);
+        if (klass == kClassExact && !act && autotune_enabled() && tuned_solution(dev, hints->a_type, b_type, m, n, k, kClassExact) == 0) {
+            // candidates are limited to the scratch THIS call can use: its own, else the registered workspace if it serves this stream
+            void *tws = call_ws;
+            uint64_t tws_bytes = call_ws ? call_ws_bytes : 0;
+            if (!tws) {
+                bool busy = false;
+                const uint64_t reg = g_workspace[dev].bytes.load();
+                tws = reg ? registered_workspace(dev, stream, reg, &busy) : nullptr;
+                tws_bytes = tws ? reg : 0;
+            }
+            autotune_on_first_sight(b_type, c, a, b, scales, global_scale, m, n, k, hints->a_type, tws, tws_bytes, stream);
+        }
         const AutoChoice ch = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k, klass, restrict_);
         entry = ch.entry, splitk = ch.splitk;
         if (!entry)
@@ -616,10 +626,21 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             if (busy && !is_auto)
                 return kErrBadArgument; // the registered workspace is bound to another stream: pass one per call
         }
-        if (!ws && klass != kClassExact && splitk > 1 && (have_qa || (call_ws && call_ws_bytes >= workspace_need(*entry, 1, m, n, k)))) {
-            splitk = 1; // native default pick with a K split, scratch covers the activations only (or they came quantised): the same kernel unsplit
-            need = workspace_need(*entry, 1, m, n, k, have_qa);
-            ws = need ? call_ws : nullptr;
+        if (!ws && klass != kClassExact && is_auto && splitk > 1) {
+            // native default pick with a K split, scratch (per call or registered) covers the activations only, or they came quantised: the
+            // same kernel unsplit -- what petit_gemm_resolve_solution reports for the same arguments
+            const uint64_t need1 = workspace_need(*entry, 1, m, n, k, have_qa);
+            void *ws1 = nullptr;
+            if (!need1) {
+                splitk = 1, need = 0;
+            } else if (call_ws) {
+                ws1 = call_ws_bytes >= need1 ? call_ws : nullptr;
+            } else {
+                bool busy = false;
+                ws1 = registered_workspace(dev, stream, need1, &busy);
+            }
+            if (ws1)
+                splitk = 1, need = need1, ws = ws1;
         }
         if (!ws && need) {
             if (!is_auto || klass != kClassExact)

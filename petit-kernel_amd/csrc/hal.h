@@ -52,7 +52,12 @@ int solution_class(uint64_t solution);
 // Add (or replace) a row at run time; thread safe; bumps tuned_generation() so cached default picks are re-derived.
 void tuned_insert(const TunedEntry &e);
 uint64_t tuned_generation();
-// Write every run-time and tune-file row (not the built-in table) in the $PETIT_AMD_TUNE_FILE format; false on I/O error.
+// false when tuned_solution() can never answer for this device ($PETIT_AMD_NO_TUNED=1, or not the arch the tables were measured on):
+// tuning on first sight would then repeat on every call and its result would never be used
+bool tuned_lookup_enabled(int device);
+// Write every run-time and tune-file row (not the built-in table) in the $PETIT_AMD_TUNE_FILE format; false on I/O error.  Several
+// processes may share one file (TP ranks with $PETIT_AMD_AUTOTUNE=1): the rows already in the file are merged in (this process's rows win
+// where they overlap) under an advisory lock on "<path>.lock", and the file is replaced by rename(), never rewritten in place.
 bool tuned_save(const char *path);
 
 } // namespace petit_amd

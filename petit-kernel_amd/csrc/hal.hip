@@ -6,8 +6,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "petit_internal.h"
@@ -83,26 +88,62 @@ TunedEntry canonical_row(TunedEntry e) {
     return e;
 }
 
-void load_override() {
-    const char *path = getenv("PETIT_AMD_TUNE_FILE");
-    if (!path || !*path)
-        return;
+// the rows of a tune file, in file order (a row naming a native-FP4 kernel lands in the native class by its id: never a plain default)
+std::vector<TunedEntry> read_rows(const char *path) {
+    std::vector<TunedEntry> rows;
     FILE *f = fopen(path, "r");
     if (!f)
-        return;
+        return rows;
     char line[256];
-    std::lock_guard<std::mutex> lock(g_rows_mutex);
     while (fgets(line, sizeof(line), f)) {
         if (line[0] == '#' || line[0] == '\n')
             continue;
         TunedEntry e{};
         unsigned long long sol = 0;
-        if (sscanf(line, "%d %d %u %u %u %u %llx", &e.a_type, &e.b_type, &e.n, &e.k, &e.m_lo, &e.m_hi, &sol) == 7) {
+        if (sscanf(line, "%d %d %u %u %u %u %llx", &e.a_type, &e.b_type, &e.n, &e.k, &e.m_lo, &e.m_hi, &sol) == 7 && e.m_lo >= 1 && e.m_hi >= e.m_lo) {
             e.solution = sol;
-            g_override.push_back(canonical_row(e)); // (a row naming a native-FP4 kernel lands in the native class by its id: never a plain default)
+            rows.push_back(canonical_row(e));
         }
     }
     fclose(f);
+    return rows;
+}
+
+void load_override() {
+    const char *path = getenv("PETIT_AMD_TUNE_FILE");
+    if (!path || !*path)
+        return;
+    std::vector<TunedEntry> rows = read_rows(path);
+    std::lock_guard<std::mutex> lock(g_rows_mutex);
+    g_override.insert(g_override.end(), rows.begin(), rows.end());
+}
+
+bool same_problem(const TunedEntry &a, const TunedEntry &b) {
+    return a.a_type == b.a_type && a.b_type == b.b_type && a.n == b.n && a.k == b.k && solution_class(a.solution) == solution_class(b.solution);
+}
+// put `e` in front of `rows`; a row of the same problem and class that it overlaps keeps the part of its M range that `e` does not cover
+// (a single-M row inserted into a 5-8 bucket leaves 5-6 and 8 with the bucket's kernel, not with nothing)
+void insert_row(std::vector<TunedEntry> &rows, const TunedEntry &e) {
+    std::vector<TunedEntry> out;
+    out.reserve(rows.size() + 3);
+    out.push_back(e);
+    for (const TunedEntry &o : rows) {
+        if (!same_problem(o, e) || o.m_hi < e.m_lo || o.m_lo > e.m_hi) {
+            out.push_back(o);
+            continue;
+        }
+        if (o.m_lo < e.m_lo) {
+            TunedEntry left = o;
+            left.m_hi = e.m_lo - 1;
+            out.push_back(left);
+        }
+        if (o.m_hi > e.m_hi) {
+            TunedEntry right = o;
+            right.m_lo = e.m_hi + 1;
+            out.push_back(right);
+        }
+    }
+    rows.swap(out);
 }
 
 bool matches(const TunedEntry &e, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass) {
@@ -133,41 +174,54 @@ void tuned_insert(const TunedEntry &row) {
     std::call_once(g_override_once, load_override);
     {
         std::lock_guard<std::mutex> lock(g_rows_mutex);
-        const int klass = solution_class(e.solution);
-        for (size_t i = 0; i < g_override.size();) { // a new row replaces the rows of the same problem and class it overlaps
-            const TunedEntry &o = g_override[i];
-            if (o.a_type == e.a_type && o.b_type == e.b_type && o.n == e.n && o.k == e.k && solution_class(o.solution) == klass &&
-                !(o.m_hi < e.m_lo || o.m_lo > e.m_hi))
-                g_override.erase(g_override.begin() + (long)i);
-            else
-                ++i;
-        }
-        g_override.insert(g_override.begin(), e);
+        insert_row(g_override, e);
     }
     g_generation.fetch_add(1, std::memory_order_acq_rel);
 }
 
 bool tuned_save(const char *path) {
     std::call_once(g_override_once, load_override);
-    FILE *f = path && *path ? fopen(path, "w") : nullptr;
-    if (!f)
+    if (!path || !*path)
         return false;
-    fprintf(f, "# a_type b_type n k m_lo m_hi solution   (petit-kernel_amd tune file; $PETIT_AMD_TUNE_FILE)\n");
-    std::lock_guard<std::mutex> lock(g_rows_mutex);
-    for (const TunedEntry &e : g_override)
-        fprintf(f, "%d %d %u %u %u %u %llx\n", e.a_type, e.b_type, e.n, e.k, e.m_lo, e.m_hi, (unsigned long long)e.solution);
-    return fclose(f) == 0;
+    const std::string target(path), lock_path = target + ".lock", tmp = target + ".tmp." + std::to_string((long)getpid());
+    // advisory lock shared by every process that saves to this file (kept for the read-merge-rename sequence; released by close)
+    const int lock_fd = open(lock_path.c_str(), O_CREAT | O_RDWR, 0644);
+    if (lock_fd >= 0)
+        (void)flock(lock_fd, LOCK_EX);
+    std::vector<TunedEntry> rows = read_rows(path); // what other processes have saved meanwhile (empty when the file does not exist yet)
+    {
+        std::lock_guard<std::mutex> lock(g_rows_mutex);
+        for (auto it = g_override.rbegin(); it != g_override.rend(); ++it) // oldest first, so that this process's newest rows end up in front
+            insert_row(rows, *it);
+    }
+    bool ok = false;
+    if (FILE *f = fopen(tmp.c_str(), "w")) {
+        fprintf(f, "# a_type b_type n k m_lo m_hi solution   (petit-kernel_amd tune file; $PETIT_AMD_TUNE_FILE)\n");
+        for (const TunedEntry &e : rows)
+            fprintf(f, "%d %d %u %u %u %u %llx\n", e.a_type, e.b_type, e.n, e.k, e.m_lo, e.m_hi, (unsigned long long)e.solution);
+        ok = fclose(f) == 0 && rename(tmp.c_str(), path) == 0;
+        if (!ok)
+            (void)unlink(tmp.c_str());
+    }
+    if (lock_fd >= 0)
+        close(lock_fd);
+    return ok;
 }
 
-uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass) {
-    // tuned ids are only meaningful on the arch they were measured on
-    if (strcmp(arch_info(device).name, "gfx950") != 0)
-        return 0;
+static bool tuned_disabled_by_env() {
     static const bool disabled = [] { // $PETIT_AMD_NO_TUNED=1: heuristic only (tools/check_heuristic.py measures what that costs)
         const char *e = getenv("PETIT_AMD_NO_TUNED");
         return e && *e && *e != '0';
     }();
-    if (disabled)
+    return disabled;
+}
+bool tuned_lookup_enabled(int device) {
+    // tuned ids are only meaningful on the arch they were measured on
+    return strcmp(arch_info(device).name, "gfx950") == 0 && !tuned_disabled_by_env();
+}
+
+uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass) {
+    if (!tuned_lookup_enabled(device))
         return 0;
     b_type = canonical_b_type(b_type);
     std::call_once(g_override_once, load_override);

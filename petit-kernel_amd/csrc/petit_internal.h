@@ -110,7 +110,7 @@ struct TuneRequest {
 int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us);
 bool autotune_enabled();
 void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *gs, unsigned m,
-                             unsigned n, unsigned k, int a_type, void *stream);
+                             unsigned n, unsigned k, int a_type, void *ws, uint64_t ws_bytes, void *stream);
 
 // repack.hip
 int repack_weights(void *out, const void *in, unsigned k, unsigned n, hipStream_t stream);

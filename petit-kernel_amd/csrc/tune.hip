@@ -76,9 +76,47 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const unsigned short *x, siz
     }
 }
 
-struct DeviceBuffers { // everything the tuner allocated itself; freed on every exit path
+// A tuning run inside a serving process must not disturb a stream capture in progress on ANOTHER stream (the library can only ask about its
+// own).  Measured (tools/probes/capture_legal.hip, ROCm 7.2): while any stream captures in global mode -- what torch.cuda.graph uses -- a
+// thread's hipStreamSynchronize / hipEventSynchronize / hipEventQuery on an unrelated stream, hipMalloc, hipFree and hipHostMalloc all fail
+// with hipErrorStreamCaptureUnsupported AND invalidate that capture; with the thread's capture mode exchanged to
+// hipStreamCaptureModeRelaxed around them they all succeed and the capture survives (only hipMemcpy and hipDeviceSynchronize stay illegal:
+// the tuner uses neither).  RelaxedCaptureMode is that exchange, for the duration of a run.
+struct RelaxedCaptureMode {
+    hipStreamCaptureMode prev = hipStreamCaptureModeRelaxed;
+    bool ok;
+    RelaxedCaptureMode() { ok = hipThreadExchangeStreamCaptureMode(&prev) == hipSuccess; } // prev: the thread's previous mode
+    ~RelaxedCaptureMode() {
+        if (ok)
+            (void)hipThreadExchangeStreamCaptureMode(&prev);
+    }
+};
+
+// Device memory of one tuning run.  Two sources:
+//  * the pool the caller reserved with petit_tune_reserve (a bump allocator over it): no hipMalloc / hipFree of hundreds of megabytes
+//    inside a GEMM call, and it works when the process's allocator already owns the whole device;
+//  * hipMalloc for whatever the pool does not cover; everything is freed on every exit path.
+struct TunePool {
+    std::mutex busy;              // one tuning run at a time per device
+    void *base = nullptr;
+    uint64_t bytes = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr; // created with the pool, so that a run creates nothing
+    unsigned *host = nullptr;     // 4 pinned words: results come back without a pageable staging copy
+};
+constexpr int kMaxTuneDevices = 64;
+TunePool g_pool[kMaxTuneDevices];
+
+struct DeviceBuffers {
     std::vector<void *> ptrs;
+    char *pool = nullptr;
+    uint64_t pool_left = 0;
     void *alloc(size_t bytes) {
+        const uint64_t need = (bytes + 255) & ~(uint64_t)255;
+        if (pool && need <= pool_left) {
+            void *p = pool;
+            pool += need, pool_left -= need;
+            return p;
+        }
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) {
             (void)hipGetLastError();
@@ -92,6 +130,34 @@ struct DeviceBuffers { // everything the tuner allocated itself; freed on every 
             (void)hipFree(p);
     }
 };
+struct EventPair { // a run's two events: the pool's, or its own (destroyed on every exit path)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool own = false;
+    bool create() {
+        own = true;
+        if (hipEventCreate(&e0) != hipSuccess) {
+            e0 = nullptr;
+            return false;
+        }
+        if (hipEventCreate(&e1) != hipSuccess) {
+            e1 = nullptr;
+            return false;
+        }
+        return true;
+    }
+    ~EventPair() {
+        if (own && e0)
+            (void)hipEventDestroy(e0);
+        if (own && e1)
+            (void)hipEventDestroy(e1);
+    }
+};
+int tune_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxTuneDevices)
+        return 0;
+    return dev;
+}
 
 bool env_on(const char *name) {
     const char *e = getenv(name);
@@ -121,6 +187,7 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
     if (!rq.c || !rq.a || !rq.gs || !rq.b || !rq.s || rq.n_copies == 0 || rq.m == 0)
         return kErrBadArgument;
     hipStream_t stream = (hipStream_t)rq.stream;
+    const RelaxedCaptureMode relaxed; // a capture on some OTHER stream survives this run (see above)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
         return kErrBadArgument; // tuning synchronises and allocates: never inside a graph capture
@@ -131,7 +198,13 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
     if (count == 0)
         return kErrKernelShape;
 
+    // the reserved pool of this device, when there is one and no other run holds it
+    TunePool &pool = g_pool[tune_device()];
+    std::unique_lock<std::mutex> pool_lock(pool.busy, std::try_to_lock);
+    const bool have_pool = pool_lock.owns_lock() && pool.base;
     DeviceBuffers mem;
+    if (have_pool)
+        mem.pool = (char *)pool.base, mem.pool_left = pool.bytes;
     const size_t out_elems = (size_t)rq.m * rq.n;
     unsigned short *c_ref = (unsigned short *)mem.alloc(out_elems * 2);
     unsigned *bad = (unsigned *)mem.alloc(sizeof(unsigned));
@@ -170,18 +243,26 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
     };
     // reference output: candidate 0 (tune_candidates puts the class's reference kernel first), and its rms: the floor of the comparison
     float *stats = (float *)mem.alloc(2 * sizeof(float));
-    float host_stats[2] = {0.f, 0.f};
+    float stack_stats[2] = {0.f, 0.f};
+    unsigned stack_bad = 1;
+    // results come back into the pool's pinned words when there is a pool (a copy into pageable memory is staged by the runtime)
+    float *host_stats = have_pool && pool.host ? reinterpret_cast<float *>(pool.host) : stack_stats;
+    unsigned *host_bad = have_pool && pool.host ? pool.host + 2 : &stack_bad;
+    host_stats[0] = host_stats[1] = 0.f;
     if (!stats || run(ids[0], c_ref, 0) != kOk || hipMemsetAsync(stats, 0, 2 * sizeof(float), stream) != hipSuccess)
         return kErrLaunch;
     hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, stream, c_ref, out_elems, rq.a_type == kDataTypeBf16 ? 1 : 0, stats);
-    if (hipMemcpyAsync(host_stats, stats, sizeof(host_stats), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+    if (hipMemcpyAsync(host_stats, stats, 2 * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
         return kErrLaunch;
     const float ref_rms = host_stats[1] > 0.f ? sqrtf(host_stats[0] / host_stats[1]) * 1024.0f : 1.0f;
     const float cmp_floor = ref_rms > 0.f ? ref_rms : 1.0f;
 
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    EventPair ev;
+    if (have_pool && pool.e0 && pool.e1)
+        ev.e0 = pool.e0, ev.e1 = pool.e1;
+    else if (!ev.create())
         return kErrLaunch;
+    const hipEvent_t e0 = ev.e0, e1 = ev.e1;
     const float tol = rq.tolerance > 0.f ? rq.tolerance : 2e-2f;
     const unsigned samples = rq.samples ? rq.samples : 5;
     uint64_t best = 0;
@@ -195,13 +276,13 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
             continue; // (a candidate the launcher refuses -- e.g. a grid limit -- is simply not ranked)
         hipLaunchKernelGGL(compare_outputs_kernel, dim3(512), dim3(256), 0, stream, (const unsigned short *)rq.c, c_ref, out_elems,
                            rq.a_type == kDataTypeBf16 ? 1 : 0, tol, cmp_floor, bad);
-        unsigned nbad = 1;
-        if (hipMemcpyAsync(&nbad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        *host_bad = 1;
+        if (hipMemcpyAsync(host_bad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess ||
             hipStreamSynchronize(stream) != hipSuccess) {
             rc = kErrLaunch;
             break;
         }
-        if (nbad)
+        if (*host_bad)
             continue;
         // 2. timing: one untimed sample sizes the batch, then `samples` timed ones
         unsigned launches = rq.launches;
@@ -236,8 +317,6 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
         if (us.size() >= samples / 2 + 1 && med < best_t)
             best_t = med, best = id;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (rc != kOk)
         return rc;
     if (!best)
@@ -258,45 +337,50 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
     return kOk;
 }
 
-// $PETIT_AMD_AUTOTUNE=1: PETIT_SOLUTION_AUTO tunes a problem whose (dtypes, N, K, M bucket) no table knows, once, on first
-// sight, with the caller's own buffers (the output is overwritten by candidates and then by the real call), clones of the
-// caller's weights for the rotation and scratch of its own; the row lands in the run-time table and, when
-// $PETIT_AMD_TUNE_FILE is set, in that file (rewritten with all run-time rows) for the next process.
+// $PETIT_AMD_AUTOTUNE=1: PETIT_SOLUTION_AUTO tunes a problem whose (dtypes, N, K, M bucket) no table knows, once, on first sight, with the
+// caller's own buffers (the output is overwritten by candidates and then by the real call) and the scratch of THAT call (so the winner
+// is a kernel this caller can run).  Everything else -- the reference output, clones of the caller's weights for the rotation -- comes
+// out of the pool reserved with petit_tune_reserve, else from hipMalloc; the run happens with the thread's capture mode relaxed, so a
+// capture in progress on another stream survives it (RelaxedCaptureMode above).  Once per key and process, whatever the outcome.  The
+// row lands in the run-time table and, when $PETIT_AMD_TUNE_FILE is set, in that file (merged with what other processes saved, hal.hip
+// tuned_save) for the next process.
 bool autotune_enabled() {
     static const bool on = env_on("PETIT_AMD_AUTOTUNE");
     return on;
 }
 void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *gs, unsigned m,
-                             unsigned n, unsigned k, int a_type, void *stream) {
+                             unsigned n, unsigned k, int a_type, void *ws, uint64_t ws_bytes, void *stream) {
+    const int dev = tune_device();
+    if (!tuned_lookup_enabled(dev))
+        return; // the table is switched off or belongs to another arch: a tuned row would never be looked up
     const void *bp = b, *sp = scales;
     TuneRequest rq{};
     rq.c = c, rq.a = a, rq.b = &bp, rq.s = &sp, rq.n_copies = 1, rq.gs = gs;
-    rq.m = m, rq.n = n, rq.k = k, rq.a_type = a_type, rq.b_type = b_type, rq.klass = 0;
-    rq.own_workspace = true, rq.stream = stream, rq.persist = true;
-    rq.rotate_bytes = (size_t)384 << 20; // past the 256 MB Infinity Cache
-    // a problem whose tuning failed (out of device memory for the clones, a capture in progress on another stream of the graph, ...)
-    // is not retried on every call: remember its key for the life of the process
+    rq.m = m, rq.n = n, rq.k = k, rq.a_type = a_type, rq.b_type = canonical_b_type(b_type), rq.klass = 0;
+    rq.own_workspace = false, rq.ws = ws, rq.ws_bytes = ws ? ws_bytes : 0; // the candidates: what THIS caller's scratch can run
+    rq.stream = stream, rq.persist = true;
+    rq.rotate_bytes = (size_t)384 << 20; // past the 256 MB Infinity Cache (as far as the pool reaches)
+    // A key is tried ONCE per process, whatever the outcome: a failure (out of memory, a capture in progress on this stream, ...) must not be
+    // retried on every call, and neither must a success whose row some later lookup does not find (e.g. a row split by a later insert).
     struct Key {
         int a_type, b_type;
         unsigned n, k, m_lo;
     };
-    static std::mutex failed_mutex;
-    static std::vector<Key> failed;
+    static std::mutex seen_mutex;
+    static std::vector<Key> seen;
     unsigned lo, hi;
     tune_bucket(m, 0, &lo, &hi);
     {
-        std::lock_guard<std::mutex> lock(failed_mutex);
-        for (const Key &f : failed)
-            if (f.a_type == a_type && f.b_type == b_type && f.n == n && f.k == k && f.m_lo == lo)
+        std::lock_guard<std::mutex> lock(seen_mutex);
+        for (const Key &f : seen)
+            if (f.a_type == a_type && f.b_type == rq.b_type && f.n == n && f.k == k && f.m_lo == lo)
                 return;
+        seen.push_back(Key{a_type, rq.b_type, n, k, lo});
     }
     uint64_t best = 0;
     float us = 0.f;
-    if (tune_problem(rq, &best, &us) != kOk) {
-        std::lock_guard<std::mutex> lock(failed_mutex);
-        failed.push_back(Key{a_type, b_type, n, k, lo});
+    if (tune_problem(rq, &best, &us) != kOk)
         return;
-    }
     const char *path = getenv("PETIT_AMD_TUNE_FILE");
     if (path && *path)
         (void)tuned_save(path);
@@ -319,7 +403,7 @@ int petit_gemm_tune(unsigned *c, const unsigned *a, const float *global_scale, u
         return kErrBadArgument;
     TuneRequest rq{};
     rq.c = c, rq.a = a, rq.b = params->b, rq.s = params->scales, rq.n_copies = params->n_copies, rq.gs = global_scale;
-    rq.m = m, rq.n = n, rq.k = k, rq.a_type = hints->a_type, rq.b_type = hints->b_type, rq.klass = params->klass;
+    rq.m = m, rq.n = n, rq.k = k, rq.a_type = hints->a_type, rq.b_type = canonical_b_type(hints->b_type), rq.klass = params->klass;
     rq.ws = workspace, rq.ws_bytes = workspace_bytes, rq.own_workspace = false, rq.stream = stream;
     rq.launches = params->launches, rq.samples = params->samples, rq.tolerance = params->tolerance;
     rq.persist = params->persist != 0, rq.m_lo = params->m_lo, rq.m_hi = params->m_hi;
@@ -336,6 +420,26 @@ int petit_tune_insert(const petit_solution_hints *hints, unsigned n, unsigned k,
     TunedEntry e{};
     e.a_type = hints->a_type, e.b_type = hints->b_type, e.n = n, e.k = k, e.m_lo = m_lo, e.m_hi = m_hi, e.solution = solution;
     tuned_insert(e);
+    return kOk;
+}
+
+int petit_tune_reserve(void *device_ptr, uint64_t bytes) {
+    if (((uintptr_t)device_ptr & 255) || (!device_ptr && bytes))
+        return kErrBadArgument;
+    TunePool &pool = g_pool[tune_device()];
+    std::lock_guard<std::mutex> lock(pool.busy); // (waits for a run in progress)
+    pool.base = device_ptr, pool.bytes = device_ptr ? bytes : 0;
+    if (device_ptr && !pool.e0) { // the per-device helpers of a run, created here so that a run creates nothing
+        if (hipEventCreate(&pool.e0) != hipSuccess)
+            pool.e0 = nullptr;
+        if (hipEventCreate(&pool.e1) != hipSuccess)
+            pool.e1 = nullptr;
+        void *h = nullptr;
+        if (hipHostMalloc(&h, 4 * sizeof(unsigned), hipHostMallocDefault) == hipSuccess)
+            pool.host = (unsigned *)h;
+        else
+            (void)hipGetLastError();
+    }
     return kOk;
 }
 

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "petit_quantize_activations": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_void_p]),
     "petit_gemm_tune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.POINTER(SolutionHints),
                                   C.POINTER(TuneParams), C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_float)]),
+    "petit_tune_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
     "petit_tune_insert": (C.c_int, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint64]),
     "petit_tune_save": (C.c_int, [C.c_char_p]),
     "petit_tune_generation": (C.c_uint64, []),

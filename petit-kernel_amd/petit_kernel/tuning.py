@@ -10,7 +10,8 @@ the library and its result feeds `solution_id = -1` directly:
 
 Every candidate's output is checked against the class's reference kernel before it is timed; launches rotate over enough
 distinct weight copies that the 256 MB Infinity Cache cannot serve them.  `PETIT_AMD_AUTOTUNE=1` does the same implicitly
-on the first `solution_id = -1` call of a shape no table knows.
+on the first `solution_id = -1` call of a shape no table knows; `reserve()` hands the tuner a memory pool so that such a
+call allocates nothing (optional).  A tuning run leaves a graph capture in progress on another stream intact.
 """
 from __future__ import annotations
 
@@ -21,6 +22,28 @@ import torch
 from . import _lib
 
 _KLASS = {"exact": 0, "native_mxfp8": 8, "native_mxfp4": 4}
+
+_reserved = {}   # device index -> the tensor the library's tuner draws from (kept alive here)
+
+
+def reserve(megabytes: int = None, device=None) -> None:
+    """Give the library's tuner a memory pool on `device` (petit_tune_reserve): what a tuning run ($PETIT_AMD_AUTOTUNE=1, tune_tensors)
+    takes its reference output and its rotation of weight clones from instead of hipMalloc.  Optional; call it at start-up, outside any
+    graph capture; default size $PETIT_AMD_AUTOTUNE_RESERVE_MB or 640 MB.  reserve(0) releases the pool."""
+    import os
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if megabytes is None:
+        megabytes = int(os.environ.get("PETIT_AMD_AUTOTUNE_RESERVE_MB", "640"))
+    with torch.cuda.device(dev):
+        if megabytes <= 0:
+            _lib.lib.petit_tune_reserve(None, 0)
+            _reserved.pop(dev.index, None)
+            return
+        buf = torch.empty(megabytes << 20, dtype=torch.uint8, device=dev)
+        rc = _lib.lib.petit_tune_reserve(C.c_void_p(buf.data_ptr()), C.c_uint64(buf.numel()))
+        if rc != _lib.PETIT_OK:
+            raise RuntimeError(f"petit_tune_reserve: {_lib.error_string(rc)}")
+        _reserved[dev.index] = buf
 
 
 def _hints(dtype, kind: str) -> _lib.SolutionHints:

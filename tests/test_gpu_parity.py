@@ -1648,9 +1648,11 @@ def test_inlib_tune_ranks_large_m_kernels_on_wide_range_mx_outputs(pk):
 
 
 def test_autotune_on_first_sight(pk, tmp_path):
-    """$PETIT_AMD_AUTOTUNE=1 + $PETIT_AMD_TUNE_FILE: the first solution_id = -1 call of an unseen shape tunes it in place (own
-    scratch, clones of the caller's weights), returns the right result, and leaves a row in the file; the second call and a
-    graph capture run without tuning again."""
+    """$PETIT_AMD_AUTOTUNE=1 + $PETIT_AMD_TUNE_FILE: the first solution_id = -1 call of an unseen shape tunes it in place (the call's own
+    scratch, clones of the caller's weights out of the reserved pool), returns the right result, and leaves a row in the file; the second
+    call and a graph capture run without tuning again; a first-sight tune on one stream while ANOTHER stream is inside torch.cuda.graph
+    leaves that capture intact (the run exchanges the thread's capture mode to relaxed: tools/probes/capture_legal.hip), without a reserved
+    pool (hipMalloc) and with one; rows another process saved meanwhile survive the save."""
     import os
     import subprocess
     import sys
@@ -1687,14 +1689,51 @@ gr = torch.cuda.CUDAGraph()
 with torch.cuda.graph(gr):
     pk.mul_nvfp4_a16(a9, b, sp, gs, 9, n, k, -1)      # same M bucket (9..16): served by the row, nothing to tune under capture
 gr.replay(); torch.cuda.synchronize()
+# --- a first-sight tune while another stream is being captured (global capture mode: what torch.cuda.graph uses).  Through the C ABI with
+# preallocated output and scratch: torch's own allocator calls a plain hipMalloc for an allocation on a stream that is not the capturing
+# one (and torch.cuda.graph empties its cache on entry), which breaks the capture before the library is even called.
+import ctypes as C
+def c_abi_call(a_, c_, ws_, m_):
+    hh = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    rc = _lib.lib.petit_gemm_fp4_fp16_grid_ws(C.c_void_p(c_.data_ptr()), C.c_void_p(a_.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(sp.data_ptr()),
+                                              C.c_void_p(gs.data_ptr()), m_, n, k, C.byref(hh), C.c_uint64(_lib.PETIT_SOLUTION_AUTO), None,
+                                              C.c_void_p(ws_.data_ptr()), C.c_uint64(ws_.numel()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+side, other = torch.cuda.Stream(), torch.cuda.Stream()
+x = torch.ones(4096, device='cuda')
+for m2, reserve_mb in ((40, 0), (100, 512)):      # M buckets 33..64 and 65..128: unseen; without and with a reserved pool (petit_tune_reserve)
+    a2 = torch.randn((m2, k), generator=g).bfloat16().cuda()
+    c2_ = torch.empty((m2, n), dtype=torch.bfloat16, device='cuda')
+    ws2 = torch.empty(32 << 20, dtype=torch.uint8, device='cuda')
+    if reserve_mb:
+        pk.tuning.reserve(reserve_mb)
+    gen_before = _lib.lib.petit_tune_generation()
+    other.wait_stream(torch.cuda.current_stream()); torch.cuda.synchronize()
+    gr2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr2, stream=side):
+        y = x * 2 + 1
+        with torch.cuda.stream(other):         # not the capturing stream
+            c_abi_call(a2, c2_, ws2, m2)
+        z = y * 3
+    assert _lib.lib.petit_tune_generation() == gen_before + 1, 'the unseen bucket must have been tuned during the capture'
+    other.synchronize()
+    ref2 = a2.float() @ dense.t()
+    assert torch.allclose(c2_.float(), ref2, rtol=1e-2, atol=1e-2 * ref2.abs().max().item())
+    x.fill_(2.0); gr2.replay(); torch.cuda.synchronize()
+    assert torch.equal(z, torch.full_like(z, 15.0)), 'the capture on the other stream must have survived the tune'
+    x.fill_(1.0)
+pk.tuning.reserve(0)
 print('%%x' %% picked)
 """ % (ROOT / "petit-kernel_amd", ROOT)
+    path.write_text("# saved by another process\n5 3 777 1024 1 1 abc\n")
     env = dict(os.environ, PETIT_AMD_AUTOTUNE="1", PETIT_AMD_TUNE_FILE=str(path))
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     picked = out.stdout.strip().splitlines()[-1]
     rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
-    assert ["5", "3", "1536", "3072"] == rows[0][:4] and rows[0][6] == picked
+    assert {tuple(r[:6]) for r in rows} >= {("5", "3", "1536", "3072", "9", "16"), ("5", "3", "1536", "3072", "33", "64"), ("5", "3", "1536", "3072", "65", "128")}
+    assert [r[6] for r in rows if r[4] == "9"] == [picked]
+    assert ["5", "3", "777", "1024", "1", "1", "abc"] in rows, "a row another process saved must survive this process's save"
 
 
 # --- the native class as a pipeline: pre-quantised activations in, quantised SiLU-mul out (petit_gemm_mxfp4_native) --------

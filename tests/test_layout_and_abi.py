@@ -485,6 +485,48 @@ print('%%x' %% pick)
     assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(path)}, _lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, 100, 3072, 5120) == pick
 
 
+def test_tune_rows_split_on_overlap_and_merge_on_save(tmp_path):
+    """A single-M row inserted into a bucket row keeps the bucket's pick for the other Ms (round 3 erased the whole bucket); petit_tune_save
+    merges with what another process wrote to the same file meanwhile and replaces the file by rename (no temp file left, a lock file
+    beside it); a tune file written by round 3 (b_type 8, element nibble 3) still loads, as plain MXFP4."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, r'%s')
+from petit_kernel import _lib
+L = _lib.lib
+at, bt, n, k = _lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, 3072, 5120
+h = _lib.SolutionHints(at, bt, at, 0)
+cnt = C.c_uint(0); L.petit_gemm_get_solutions(C.byref(h), 8, n, k, None, C.byref(cnt))
+ids = (C.c_uint64 * cnt.value)(); L.petit_gemm_get_solutions(C.byref(h), 8, n, k, ids, C.byref(cnt))
+ids = [i for i in ids if (i >> 48) & 0xF in (10, 11)]            # staged 8 / 16 rows: can serve the whole 5..8 bucket
+bucket, single = ids[0], ids[1]
+assert L.petit_tune_insert(C.byref(h), n, k, 5, 8, C.c_uint64(bucket)) == 0
+assert L.petit_tune_insert(C.byref(h), n, k, 7, 7, C.c_uint64(single)) == 0
+picks = [L.petit_gemm_default_solution(C.byref(h), m, n, k) for m in (5, 6, 7, 8)]
+assert picks == [bucket, bucket, single, bucket], [hex(p) for p in picks]
+# round 3's spelling of fp16 x MXFP4 with fp16-safe scales: b_type 8, element nibble 3
+h16 = _lib.SolutionHints(_lib.CXX_DTYPE_FP16, _lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_FP16, 0)
+old = L.petit_gemm_default_solution(C.byref(h16), 16, 2048, 4096)
+print('%%x %%x %%x' %% (bucket, single, old))
+assert L.petit_tune_save(sys.argv[1].encode()) == 0
+""" % (ROOT / "petit-kernel_amd")
+    path = tmp_path / "shared.txt"
+    path.write_text("# another rank\n5 3 9999 1024 1 1 1814411013100101\n4 8 2048 4096 9 16 181b811033100101\n")
+    out = subprocess.run([sys.executable, "-c", code, str(path)], env=dict(os.environ, PETIT_AMD_TUNE_FILE=str(path)), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    bucket, single, old = (int(x, 16) for x in out.stdout.strip().splitlines()[-1].split())
+    assert old == 0x181b811023100101                                  # the round-3 row was read as b_type 7 / nibble 2 and served the query
+    rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
+    mine = sorted((int(r[4]), int(r[5]), int(r[6], 16)) for r in rows if r[2] == "3072")
+    assert mine == [(5, 6, bucket), (7, 7, single), (8, 8, bucket)]
+    assert ["5", "3", "9999", "1024", "1", "1", "1814411013100101"] in rows      # the other rank's row survived
+    assert ["4", "7", "2048", "4096", "9", "16", "181b811023100101"] in rows
+    assert sorted(os.listdir(tmp_path)) == ["shared.txt", "shared.txt.lock"]
+
+
 def test_native_class_default_picks():
     """solution_id -2 / -3 (PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4): the pick comes from the class's own table, else its own
     model; it is always a native kernel of the requested activation format, exists for MXFP4 weights only, needs scratch, and
