@@ -171,22 +171,53 @@ double stream_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k
 // `splitk` K slices across workgroups (1 = none): each slice walks K / splitk, the grid is splitk times larger, and the fp32
 // slabs cost a second launch plus one write and one read of splitk * m * n floats (fitted on the r02 sweeps: sq8192 M = 128
 // 128x128 x4 modelled 28.4 us / measured 28.8; down M = 128 128x128 x8 72.7 / 75.3).
+// Step costs of the large-M kernels, FITTED (round 4: tools/fit_cost_model.py) on every candidate the in-library tuner timed while the
+// built-in table was rebuilt (profiles/r04_table_candidates.csv.gz: 92 shapes x 10 M x 4 families): t1 = the time of one k-tile step of one
+// workgroup on a full chip, resident = the workgroups a CU effectively overlaps; median |log error| of the fit 6-9 % per kernel.
+struct StepCost {
+    int a_type, fmt, kind, tile_m, nt, d, pf, kg;
+    float t1, resident, err;
+};
+const StepCost kStepCost[] = {
+#include "cost_gfx950.inc"
+};
+const StepCost *step_cost(const SolutionEntry &e) {
+    const StreamShape &s = e.shape;
+    const int kind = s.am == kTiledAm ? 8 : 12, kg = (s.am == kWideAm && s.wm == 3) ? 2 : 1, pf = s.am == kWideAm ? s.pa : 1;
+    for (const StepCost &c : kStepCost)
+        if (c.a_type == e.a_type && c.fmt == e.fmt && c.kind == kind && c.tile_m == s.mt && c.nt == s.nt && c.d == s.d && c.pf == pf && c.kg == kg)
+            return &c;
+    return nullptr;
+}
 double tiled_cost_us(const SolutionEntry &e, unsigned m, unsigned n, unsigned k, int num_cus, unsigned splitk = 1) {
     const StreamShape &s = e.shape;
+    const bool wide = s.am == kWideAm;
+    const unsigned kg = (wide && s.wm == 3) ? 2u : 1u; // K groups inside the workgroup
+    const unsigned bm = (wide ? 32u : 16u) * s.mt, per_wg = s.nt * s.wn;
+    const double wgs = (double)((m + bm - 1) / bm) * (double)((n / kTileN + per_wg - 1) / per_wg) * splitk;
+    const unsigned ks = span_tiles_for_k(k), nspans = k / (kTileK * ks), parts = splitk * kg;
+    const double steps = (double)((nspans + parts - 1) / parts) * ks; // k-tiles the longest slice walks
+    const double reduce = splitk > 1 ? 1.5 + (double)splitk * m * n * 8.0 / 5e6 : 0.0;
+    if (const StepCost *c = step_cost(e)) {
+        // rounds: dispatch is dynamic, so a grid a little over a whole number of rounds pays for part of the next round only when many
+        // rounds average it out; half way between the two readings fits the data best
+        const double r = wgs / (num_cus * (double)c->resident), rounds = r <= 1.0 ? 1.0 : 0.5 * (r + (double)(unsigned long)(r + 0.999999));
+        return 2.0 + steps * c->t1 * rounds + reduce;
+    }
+    // a kernel without a fitted row (a shape added after the last fit): the round-2 hand fit
     const int acc = s.mt * s.nt; // accumulator tiles per wave: 8 = 64x128 / 128x64, 16 = 64x256 / 128x128
     double t1 = s.mt == 4 && s.nt == 2 ? 0.71 : s.mt == 4 && s.nt == 4 ? 1.31 : s.mt == 8 && s.nt == 2 ? 1.135
               : s.mt == 8 && s.nt == 1 ? 0.94 : s.mt == 1 && s.nt == 4 ? 0.80 : s.mt == 2 && s.nt == 4 ? 0.97
-              : s.mt == 4 && s.nt == 5 ? 1.43 : s.mt == 8 && s.nt == 4 ? 1.92 : 0.09 * acc + 0.2; // (64x320: qkv M = 512 91.6 us / 64 steps; 128x256: down 215 us / 112)
+              : s.mt == 4 && s.nt == 5 ? 1.43 : s.mt == 8 && s.nt == 4 ? 1.92 : 0.09 * acc + 0.2;
+    if (wide)
+        t1 *= 2.0 * (kg == 2 ? 1.8 : 1.0);
     if (e.fmt == kFmtMx)
         t1 *= 0.75; // no group-scale multiplies in the unpack
     const double resident = (acc <= 8 || (s.mt == 8 && s.nt == 2)) ? 1.14 : 1.0;
-    const unsigned per_wg = s.nt * s.wn;
-    const double wgs = (double)((m + 16 * s.mt - 1) / (16 * s.mt)) * (double)((n / kTileN + per_wg - 1) / per_wg);
-    double rounds = wgs * splitk / (num_cus * resident);
+    double rounds = wgs / (num_cus * resident);
     if (rounds < 1.0)
         rounds = 1.0;
-    const double reduce = splitk > 1 ? 1.5 + (double)splitk * m * n * 8.0 / 5e6 : 0.0;
-    return 2.0 + (double)(k / kTileK) / splitk * t1 * rounds + reduce;
+    return 2.0 + steps * t1 * rounds + reduce;
 }
 
 // *splitk_out (when given): the heuristic may answer with a K split across workgroups for the tiled kernels (needs scratch:
@@ -214,10 +245,11 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
             const SolutionEntry &e = fam.entries[i];
             const StreamShape &s = e.shape;
             if (!entry_fits(e, m, k) || is_native_am(s.am) || s.am == kWideAm || (need_pairs && !act_ok(e)))
-                continue; // (never the native-FP4 kernels: different accuracy class; the 32x32 kernels come from the arch table)
+                continue; // (never the native-FP4 kernels: different accuracy class; the 32x32 kernels come from the arch table: the
+                          //  cost model is good to ~10 % per kernel, and an argmin over twice the candidates loses more to that noise than it gains)
             double us;
             unsigned sk = 1;
-            if (s.am == kTiledAm) {
+            if (s.am == kTiledAm || s.am == kWideAm) {
                 us = tiled_cost_us(e, m, n, k, arch.num_cus);
                 if (splitk_out && !need_pairs) { // K-heavy / narrow problems leave most CUs idle without a K split
                     for (unsigned cand = 2; cand <= 8 && cand <= nspans; cand *= 2) {
@@ -413,6 +445,15 @@ struct AutoChoice {
     const SolutionEntry *entry;
     unsigned splitk;
 };
+// how far (2 |ln n/n'| + |ln k/k'|) a tabulated shape may lie from the problem and still lend it its kernel: a factor of ~2.7 in N or ~7 in K
+constexpr double kNearestMaxDistance = 2.0;
+bool nearest_disabled() { // $PETIT_AMD_NO_NEAREST=1: unseen shapes go straight to the formula heuristic (tools/check_heuristic.py compares the two)
+    static const bool off = [] {
+        const char *e = getenv("PETIT_AMD_NO_NEAREST");
+        return e && *e && *e != '0';
+    }();
+    return off;
+}
 AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k,
                        int klass = kClassExact, unsigned restrict_ = 0) {
     struct Slot {
@@ -436,6 +477,18 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
         if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
                         (act && (!act_ok(*c.entry) || c.splitk != 1)) || !entry_allows(*c.entry, restrict_)))
             c.entry = nullptr;
+    }
+    if (!c.entry && !nearest_disabled()) {
+        // no row for this shape: the row of the nearest tabulated shape (hal.h tuned_nearest), when its kernel can run this problem
+        const uint64_t near = tuned_nearest(dev, a_type, b_type, m, n, k, klass, kNearestMaxDistance);
+        if (near) {
+            c.entry = find_entry(fam, near);
+            c.splitk = solution_splitk(near);
+            const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+            if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 || c.splitk > nspans ||
+                            (act && (!act_ok(*c.entry) || c.splitk != 1)) || !entry_allows(*c.entry, restrict_)))
+                c.entry = nullptr;
+        }
     }
     if (!c.entry)
         c.entry = klass == kClassExact ? heuristic(fam, m, n, k, act, &c.splitk)

@@ -287,7 +287,11 @@ struct Native32Cfg {
     static constexpr int BN = 32 * NP * WAVES;
     // 128 x 256 / 256 x 128 with a two-tile ring: asked to fit two workgroups per CU (256 registers, 128 of them accumulators):
     // 3/4 of the operand bytes per flop of 128 x 128 AND a second workgroup to overlap with (gate_up M = 512: 158 -> 144 us)
-    static constexpr int kMinWavesPerSimd = (KG == 2 || (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2)) ? 2 : 1; // (MXFP8 fragments are twice the size: spills)
+    // MXFP8 fragments are twice the size (the group-ahead double buffer of MB fragments is 64 registers + scales): that form reads its
+    // fragments ONE m-block ahead instead (kLean: 18 registers; an FP8-rate MFMA pair covers the LDS latency), which is what lets the
+    // 128 x 256 tile fit two workgroups per CU for MXFP8 activations too
+    static constexpr bool kLean = ACT == 8 && WM == 1 && KG == 1 && LW_ == 0 && MB * NP == 8 && D == 2;
+    static constexpr int kMinWavesPerSimd = (KG == 2 || kLean || (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2)) ? 2 : 1;
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
     static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;       // KG = 2: the second group's accumulators, f32
     static constexpr int kSmemU4a = KG * NBUF * kStageU4 > kCTileU4 ? KG * NBUF * kStageU4 : kCTileU4;
@@ -410,7 +414,20 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
         u32x4 d[MB][kFragU4];
         int s[MB];
     };
+    struct Frag1 { // kLean: one m-block's fragment
+        u32x4 d[kFragU4];
+        int s;
+    };
     const unsigned my_swz = swz(m_l); // (32 mb is a multiple of every swizzle period)
+    auto read_frag1 = [&](const u32x4 *a_cur, const unsigned char *sc_bytes, int q, int mb, Frag1 &f) {
+        const unsigned row = (wm * MB + mb) * 32 + m_l;
+#pragma unroll
+        for (int e = 0; e < kFragU4; ++e) {
+            const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
+            f.d[e] = a_cur[row * U + (unit ^ my_swz)];
+        }
+        f.s = (int)sc_bytes[row * 4 + 2 * q + h];
+    };
     auto read_frags = [&](const u32x4 *a_cur, const unsigned char *sc_bytes, int q, Frags &f) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -563,8 +580,12 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 if constexpr (!Cfg::LW)
                     dma_stage(kt + PF * KT, cur_buf == 0 ? (unsigned)(NBUF - 1) : cur_buf - 1);
             }
-            Frags fr[2];
-            read_frags(stage, stage_sc, 0, fr[0]);
+            Frags fr[Cfg::kLean ? 1 : 2];
+            Frag1 f1[2];
+            if constexpr (Cfg::kLean)
+                read_frag1(stage, stage_sc, 0, 0, f1[0]);
+            else
+                read_frags(stage, stage_sc, 0, fr[0]);
             __builtin_amdgcn_sched_barrier(0);
             int refills = 0; // W loads issued in this stage (compile-time after unrolling)
             static_for<0, KT>([&](auto t_c) {
@@ -593,15 +614,31 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 }
                 static_for<0, 2>([&](auto q_c) {
                     constexpr int q = decltype(q_c)::value, gi = 2 * TI + q; // group index inside the stage
+                    if constexpr (Cfg::kLean) {
+                        // one m-block ahead: fragment li + 1 is requested before the MFMAs of fragment li issue
+                        static_for<0, MB>([&](auto mb_c) {
+                            constexpr int mb = decltype(mb_c)::value, li = gi * MB + mb;
+                            if constexpr (li + 1 < 2 * KT * MB) {
+                                constexpr int ngi = (li + 1) / MB, nmb = (li + 1) % MB, nti = ngi / 2, nq = ngi % 2;
+                                read_frag1(stage + nti * Cfg::kDataU4, stage_sc + nti * Cfg::kScaleU4 * 16, nq, nmb, f1[(li + 1) & 1]);
+                            }
+                            const u32x4 lo = f1[li & 1].d[0], hi = f1[li & 1].d[kFragU4 - 1];
+                            const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+                            for (int np = 0; np < NP; ++np)
+                                acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, 0 /* B = FP8 e4m3 */,
+                                                                                              T % 4, (int)rec[np][q].d[T / 4], 0, f1[li & 1].s);
+                        });
+                    }
                     // fragments of the next group (next operand, or the next tile of the stage) while this group's MFMAs run
-                    if constexpr (gi + 1 < 2 * KT && !(PETIT_ABLATE_N32 & 4)) {
+                    if constexpr (!Cfg::kLean && gi + 1 < 2 * KT && !(PETIT_ABLATE_N32 & 4)) {
                         constexpr int nti = (gi + 1) / 2, nq = (gi + 1) % 2;
                         read_frags(stage + nti * Cfg::kDataU4, stage_sc + nti * Cfg::kScaleU4 * 16, nq, fr[(gi + 1) & 1]);
                     }
 #pragma unroll
-                    for (int mb = 0; mb < MB; ++mb) {
+                    for (int mb = 0; mb < (Cfg::kLean ? 0 : MB); ++mb) {
                         i32x8 aop;
-                        constexpr int fi = (PETIT_ABLATE_N32 & 4) ? 0 : (gi & 1);
+                        constexpr int fi = (PETIT_ABLATE_N32 & 4) ? 0 : (Cfg::kLean ? 0 : (gi & 1));
                         if constexpr (ACT == 8) {
                             const u32x4 lo = fr[fi].d[mb][0], hi = fr[fi].d[mb][kFragU4 - 1];
                             aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};

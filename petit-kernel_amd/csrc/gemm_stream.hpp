@@ -82,10 +82,14 @@ struct StreamCfg {
 // addresses without waiting for the s_load round trip of the kernarg segment -- the decode kernel is all prologue
 // (every wave issues its whole share of loads at once), and that round trip sits in front of all of them.
 // (block_x: the workgroup's index along N -- blockIdx.x for a plain launch, the index inside its member for a grouped one)
-template <class Cfg>
+// kCombine (gemm_stream_combine_kernel below): a K split across workgroups (gridDim.z) whose partial sums meet INSIDE the launch -- every
+// slice publishes its fp32 partial tile in its slab, takes a ticket for the output tile, and the last arriver sums the slabs in slice
+// order (deterministic) and finishes the epilogue -- instead of in a second launch (splitk_reduce_kernel).
+template <class Cfg, bool kCombine = false>
 __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *arg_s, const void *arg_a, unsigned arg_k, unsigned arg_n,
                                                  unsigned arg_m, unsigned arg_spw, unsigned arg_act, void *arg_c, const float *arg_gs,
-                                                 const void *arg_bias, float *arg_workspace, const unsigned block_x) {
+                                                 const void *arg_bias, float *arg_workspace, const unsigned block_x,
+                                                 unsigned *arg_tickets = nullptr) {
     GemmArgs p;
     p.c = arg_c, p.a = arg_a, p.w = arg_w, p.s = arg_s, p.gs = arg_gs, p.bias = arg_bias, p.act = arg_act;
     p.workspace = arg_workspace, p.m = arg_m, p.n = arg_n, p.k = arg_k, p.spans_per_wave = arg_spw, p.flags = 0;
@@ -646,6 +650,38 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
             }
         }
     }
+    if constexpr (kCombine) {
+        // Every thread's slab stores are made visible device-wide (release at agent scope: the other slices run on other XCDs, whose L2s
+        // are not coherent with this one), then ONE thread takes the workgroup's ticket for this output tile; the workgroup that draws the
+        // last ticket acquires, re-arms the counter for the next launch and sums the slabs in slice order.
+        if (gridDim.z > 1) {
+            __shared__ unsigned ticket;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                ticket = __hip_atomic_fetch_add(arg_tickets + (blockIdx.y * gridDim.x + block_x), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (ticket == gridDim.z - 1) {
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(arg_tickets + (blockIdx.y * gridDim.x + block_x), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (unsigned item = threadIdx.x; item < (unsigned)Cfg::kRedItems; item += Cfg::kThreads) {
+                    const unsigned tile = item >> 6, il = item & 63u;
+                    const unsigned iwn = tile / (MT * NT), imt = (tile / NT) % MT, inn = tile % NT;
+                    const unsigned m = m0 + imt * 16 + (il & 15u);
+                    const unsigned ntile = (block_x * WN + iwn) * NT + inn;
+                    const unsigned n = ntile * 16 + (il >> 4) * 4;
+                    if (m >= p.m || ntile >= ntiles)
+                        continue;
+                    const float *src = p.workspace + (size_t)m * p.n + n;
+                    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
+                    for (unsigned z = 1; z < gridDim.z; ++z)
+                        v += __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)z * p.m * p.n));
+                    *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
+                }
+            }
+        }
+    }
     if constexpr (ABL & 16) {
         ts[3] = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
@@ -663,6 +699,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_kernel(const void *
                                                                     const float *arg_gs, const void *arg_bias,
                                                                     float *arg_workspace) {
     gemm_stream_body<Cfg>(arg_w, arg_s, arg_a, arg_k, arg_n, arg_m, arg_spw, arg_act, arg_c, arg_gs, arg_bias, arg_workspace, blockIdx.x);
+}
+
+// The same kernel with the cross-workgroup K split combined in the launch (kCombine above); tickets: one zero-initialised counter per
+// (m-block, column block) workgroup position, left at zero by every launch.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_stream_combine_kernel(const void *arg_w, const void *arg_s, const void *arg_a,
+                                                                            unsigned arg_k, unsigned arg_n, unsigned arg_m,
+                                                                            unsigned arg_spw, unsigned arg_act, void *arg_c,
+                                                                            const float *arg_gs, const void *arg_bias,
+                                                                            float *arg_workspace, unsigned *arg_tickets) {
+    gemm_stream_body<Cfg, true>(arg_w, arg_s, arg_a, arg_k, arg_n, arg_m, arg_spw, arg_act, arg_c, arg_gs, arg_bias, arg_workspace, blockIdx.x,
+                                arg_tickets);
 }
 
 // Grouped form (see gemm_decode_grouped_kernel in gemm_decode.hpp): the members' grids concatenated along x; one m-block, no K

@@ -47,6 +47,12 @@ struct TunedEntry {
 // opt-in native class with MXFP8 / MXFP4 activations (its own table: a row naming a native kernel is never seen by klass 0).
 // Lookup order: rows added at run time (tuned_insert: petit_gemm_tune, $PETIT_AMD_AUTOTUNE), $PETIT_AMD_TUNE_FILE, built-in.
 uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass = 0);
+// No row for (n, k)?  The row of the NEAREST tabulated shape of the same dtypes, class and span size whose M range holds m:
+// distance 2 |ln(n / n')| + |ln(k / k')| (the kernel choice follows the column count -- how the grid fills the chip -- more than the
+// reduction length), 0 when nothing lies within `max_distance`.  Measured on ten shapes kept out of the table (profiles/r04_heuristic.md):
+// the neighbour's kernel is within 1 % of the best kernel in the median, 14 % at the 90th percentile; the formula-based heuristic 5 % / 24 %.
+uint64_t tuned_nearest(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, unsigned *n_found = nullptr,
+                       unsigned *k_found = nullptr);
 // class of a solution id: 0 exact, 8 / 4 native with MXFP8 / MXFP4 activations
 int solution_class(uint64_t solution);
 // Add (or replace) a row at run time; thread safe; bumps tuned_generation() so cached default picks are re-derived.

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <cmath>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -235,6 +236,38 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
         if (matches(*e, a_type, b_type, m, n, k, klass))
             return e->solution;
     return 0;
+}
+
+uint64_t tuned_nearest(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, unsigned *n_found,
+                       unsigned *k_found) {
+    if (!tuned_lookup_enabled(device) || n == 0 || k == 0)
+        return 0;
+    b_type = canonical_b_type(b_type);
+    auto span_class = [](unsigned kk) { return kk % 1024 == 0 ? 8 : kk % 512 == 0 ? 4 : 2; }; // (layout.h span_tiles_for_k: a kernel is built for one)
+    const int ks = span_class(k);
+    uint64_t best = 0;
+    double best_d = max_distance;
+    auto consider = [&](const TunedEntry &e) {
+        if (e.a_type != a_type || e.b_type != b_type || m < e.m_lo || m > e.m_hi || solution_class(e.solution) != klass || span_class(e.k) != ks)
+            return;
+        const double d = 2.0 * std::fabs(std::log((double)n / e.n)) + std::fabs(std::log((double)k / e.k));
+        if (d < best_d) {
+            best_d = d, best = e.solution;
+            if (n_found)
+                *n_found = e.n;
+            if (k_found)
+                *k_found = e.k;
+        }
+    };
+    std::call_once(g_override_once, load_override);
+    {
+        std::lock_guard<std::mutex> lock(g_rows_mutex);
+        for (const TunedEntry &e : g_override)
+            consider(e);
+    }
+    for (const TunedEntry *e = klass == 0 ? kBuiltin : kBuiltinNative; e->solution; ++e)
+        consider(*e);
+    return best;
 }
 
 } // namespace petit_amd

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -263,6 +264,12 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
     else if (!ev.create())
         return kErrLaunch;
     const hipEvent_t e0 = ev.e0, e1 = ev.e1;
+    // $PETIT_AMD_TUNE_LOG=<file>: append "a_type,b_type,klass,m,n,k,solution,us_median,samples" per timed candidate (what tools/build_table.py
+    // turns into the heuristic's fit / check data: a full sweep's worth of timings for the price of a tuning run)
+    static FILE *const tune_log = [] {
+        const char *path = getenv("PETIT_AMD_TUNE_LOG");
+        return path && *path ? fopen(path, "a") : nullptr;
+    }();
     const float tol = rq.tolerance > 0.f ? rq.tolerance : 2e-2f;
     const unsigned samples = rq.samples ? rq.samples : 5;
     uint64_t best = 0;
@@ -314,9 +321,13 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
             continue;
         std::sort(us.begin(), us.end());
         const float med = us[us.size() / 2];
+        if (tune_log) // $PETIT_AMD_TUNE_LOG: every candidate that passed its check, with the samples it got (1 = dropped as hopeless)
+            fprintf(tune_log, "%d,%d,%d,%u,%u,%u,%llx,%.3f,%zu\n", rq.a_type, rq.b_type, rq.klass, rq.m, rq.n, rq.k, (unsigned long long)id, med, us.size());
         if (us.size() >= samples / 2 + 1 && med < best_t)
             best_t = med, best = id;
     }
+    if (tune_log)
+        fflush(tune_log);
     if (rc != kOk)
         return rc;
     if (!best)

@@ -424,18 +424,57 @@ def test_compiled_ops_have_shape_functions_for_tracing():
         torch.ops.petit_kernel.repack_nvfp4(torch.zeros((n, k // 8), dtype=torch.int32), n, k)
 
 
-def test_heuristic_stays_close_to_the_measured_best():
-    """Where the arch table has no row the heuristic decides: replayed (table disabled) against every case of the
-    committed MI355X sweeps its median must stay within 1.03x of the best measured solution, 90 % of the cases within 1.2x, the worst
-    (K = 1024, a single span: three of four K-waves idle) within 1.7x."""
+def test_unseen_shapes_stay_close_to_the_measured_best():
+    """Where the arch table has no row: (1) the kernel of the NEAREST tabulated shape (hal.h tuned_nearest), replayed on the ten shapes that
+    tools/build_table.py kept out of the table against every candidate the in-library tuner timed on them on MI355X
+    (profiles/r04_table_candidates.csv.gz): within 3 % of the best kernel in the median of EVERY M bucket, 15 % at the 90th percentile
+    overall; (2) the formula heuristic behind it (table disabled), on all 3680 tabulated problems: median within 4 %, 90 % within 25 %."""
     import subprocess
     import sys
-    out = subprocess.run([sys.executable, str(ROOT / "tools" / "check_heuristic.py")], capture_output=True, text=True,
-                         check=True).stdout
-    m = re.search(r"slowdown vs best: median ([0-9.]+), p90 ([0-9.]+), max ([0-9.]+)", out)
-    assert m, out
-    median, p90, worst = (float(x) for x in m.groups())
-    assert median <= 1.03 and p90 <= 1.2 and worst <= 1.7, out
+
+    def run(*args):
+        out = subprocess.run([sys.executable, str(ROOT / "tools" / "check_heuristic.py"), *args], capture_output=True, text=True, check=True).stdout
+        m = re.search(r"slowdown vs best: median ([0-9.]+), p90 ([0-9.]+), max ([0-9.]+)", out)
+        assert m, out
+        buckets = [tuple(float(x) for x in b) for b in re.findall(r"^\| \d+-\d* \| \d+ \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \|$", out, re.M)]
+        return tuple(float(x) for x in m.groups()), buckets, out
+    (median, p90, _), buckets, out = run("--heldout", "--by-m", "--mode", "nearest")
+    assert len(buckets) == 10 and median <= 1.02 and p90 <= 1.16 and all(b[0] <= 1.03 for b in buckets), out
+    (median, p90, _), buckets, out = run("--by-m")
+    assert len(buckets) == 10 and median <= 1.04 and p90 <= 1.25 and all(b[0] <= 1.06 for b in buckets), out
+
+
+def test_builtin_tables_parse_and_name_kernels_of_this_build():
+    """csrc/tuned_gfx950.inc (>= 1500 rows: the linear shapes of seven model families at TP 1 / 2 / 4 / 8, tools/build_table.py) and
+    csrc/cost_gfx950.inc: every row parses, names a kernel this build has (petit_describe_solution) that fits the row's span size, M
+    ranges of one problem do not overlap, and the library serves each row's own problem with exactly that kernel."""
+    from petit_kernel import _lib
+    text = (ROOT / "petit-kernel_amd" / "csrc" / "tuned_gfx950.inc").read_text()
+    rows = re.findall(r"^\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\},$", text, re.M)
+    assert len(rows) >= 1500 and len(rows) == sum(1 for ln in text.splitlines() if ln.startswith("{"))
+    seen = {}
+    shapes = set()
+    for at, bt, n, k, lo, hi, sid in rows:
+        at, bt, n, k, lo, hi, sid = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sid, 16)
+        assert at in (4, 5) and bt in (3, 7) and n % 16 == 0 and k % 256 == 0 and 1 <= lo <= hi
+        assert not _lib.describe_solution(sid).startswith("unknown"), hex(sid)
+        assert (sid >> 48) & 0xF not in (9, 13)                               # never a native-FP4 kernel in the exact class's table
+        assert ((sid >> 16) & 0x1F) // 2 == (8 if k % 1024 == 0 else 4 if k % 512 == 0 else 2)
+        for (lo2, hi2) in seen.setdefault((at, bt, n, k), []):
+            assert hi < lo2 or lo > hi2, (at, bt, n, k, lo, hi)
+        seen[(at, bt, n, k)].append((lo, hi))
+        shapes.add((n, k))
+    assert len(shapes) >= 80
+    for at, bt, n, k, lo, hi, sid in rows[::37]:                              # a sample through the ABI: the row is what AUTO resolves to
+        h = _lib.SolutionHints(int(at), int(bt), int(at), 0)
+        assert _lib.lib.petit_gemm_default_solution(C.byref(h), int(lo), int(n), int(k)) == int(sid, 16)
+    cost = (ROOT / "petit-kernel_amd" / "csrc" / "cost_gfx950.inc").read_text()
+    crow = re.findall(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), ([0-9.]+)f, ([0-9.]+)f, ([0-9.]+)f\},$", cost, re.M)
+    assert len(crow) >= 40 and len(crow) == sum(1 for ln in cost.splitlines() if ln.startswith("{"))
+    assert all(0.1 < float(r[8]) < 10 and 1.0 <= float(r[9]) <= 2.0 and float(r[10]) < 0.2 for r in crow)
+    # an unseen shape takes its nearest neighbour's kernel (here: Llama-3-70B qkv for a 10368 x 8192 problem), unless that is switched off
+    h = _lib.SolutionHints(5, 3, 5, 0)
+    assert _lib.lib.petit_gemm_default_solution(C.byref(h), 16, 10368, 8192) == _lib.lib.petit_gemm_default_solution(C.byref(h), 16, 10240, 8192)
 
 
 # --- tune-and-persist plumbing (csrc/tune.hip, hal.hip): everything that needs no GPU ----------------
@@ -525,6 +564,41 @@ assert L.petit_tune_save(sys.argv[1].encode()) == 0
     assert ["5", "3", "9999", "1024", "1", "1", "1814411013100101"] in rows      # the other rank's row survived
     assert ["4", "7", "2048", "4096", "9", "16", "181b811023100101"] in rows
     assert sorted(os.listdir(tmp_path)) == ["shared.txt", "shared.txt.lock"]
+
+
+def test_bench_line_stays_inside_the_drivers_record():
+    """The driver keeps the last ~16 KB of bench.py's stdout: the whole JSON line must fit with room to spare (<= 8 KB with every cell of the
+    plan present), the metric's own 16 cells (bf16 x NVFP4, M in {1, 8, 16, 512}, the four Llama-3-70B linears) must END the line, and the
+    bf16 x MXFP4 decode cells (the reference's only MX activation type) must be in the plan.  No GPU: cells are synthesised from the plan."""
+    import importlib.util
+    import json
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import benchlib as BL
+    spec = importlib.util.spec_from_file_location("bench_for_test", ROOT / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    plan = BL.bench_cell_plan()
+    assert {(c["shape"], c["M"]) for c in plan if (c["a"], c["w"], c["mode"]) == ("bf16", "mx", "auto") and c["M"] <= 16} == \
+        {(s, m) for s in BL.SHAPE_ORDER for m in (1, 16)}
+    cells = []
+    for c in plan:
+        dt = f"{c['a']}x{c['w']}" + ("" if c["mode"] == "auto" else f" {c['mode']}")
+        cell = {"shape": c["shape"], "M": c["M"], "dt": dt, "us": 1234.56, "us_min": 1230.01, "frac": 0.6789, "sid": "1814411013100101", "kernel": "x" * 120}
+        cell["GBs" if c["M"] <= 16 else "TF"] = 4567 if c["M"] <= 16 else 1234.5
+        cells.append(cell)
+    compact = bench.compact_cells(cells)
+    line = {"metric": "bf16xnvfp4_gemm_achieved_hbm_bandwidth_m1_n8192_k8192", "value": 4690.994931410796, "unit": "GB/s", "n_gpus": 1, "steps": 20,
+            "warmup": 5, "ms_per_step": 0.00805405005812645, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic", "config": {"workload": "w" * 110, "parallelism": "replicas x1 (no data-path collective)", "solution": "s" * 130},
+            "roofline": {"bound": "hbm", "achieved": 4690.99, "peak": 8000.0, "unit": "GB/s", "frac": 0.586, "traffic": 37980000, "traffic_source": "t" * 120},
+            "host_us_per_call": {"x": "y" * 400}, "cells_method": "m" * 600, "cpu_baseline": {"value": 0.39, "unit": "GB/s", "cores": 128, "kind": "port", "sample": "s" * 200}}
+    line.update(compact)
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= 8192, len(text)
+    assert list(line)[-1] == "metric_cells" and len(compact["metric_cells"]) == 16
+    assert {(r[0], r[1]) for r in compact["metric_cells"]} == {(s, m) for s in BL.SHAPE_ORDER for m in (1, 8, 16, 512)}
+    assert all(len(r) == 6 for r in compact["metric_cells"] if r[1] <= 16)      # ... with the fraction of the 6.29 TB/s copy ceiling beside 8 TB/s
 
 
 def test_native_class_default_picks():

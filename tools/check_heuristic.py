@@ -1,56 +1,59 @@
 #!/usr/bin/env python3
-"""tools/check_heuristic.py -- how good is the heuristic of csrc/api.hip where the arch table has no row?
+"""tools/check_heuristic.py [--heldout] [--by-m] [--data FILE] -- how good is the heuristic of csrc/api.hip where the arch table has no row?
 
-For every (dtype, shape, M) of the committed sweeps (profiles/r01_sweeps.csv.gz) ask the library for its pick with the
-table disabled ($PETIT_AMD_NO_TUNED=1, no GPU needed) and look that solution up in the sweep's timings: prints the
-slowdown of the heuristic pick against the best measured solution.  Shapes outside the table get this quality."""
+For every (dtype, format, shape, M) of the committed tuner logs (profiles/r04_table_candidates.csv.gz: every candidate kernel the in-library
+tuner timed on MI355X while tools/build_table.py built the table; written by the library itself, $PETIT_AMD_TUNE_LOG) ask the library for
+its pick with the table disabled ($PETIT_AMD_NO_TUNED=1, no GPU needed) and look that kernel up in the log: prints the slowdown of the
+heuristic's pick against the best timed candidate.  --heldout: only the shapes that were kept OUT of the table (tools/build_table.py
+HELDOUT) -- what an unseen shape gets.  The K split the heuristic may add is looked up as such (a pick the tuner did not time counts as
+missing, and is listed).  Rounds 1-3 replayed the r01 sweeps here; those timed kernels that no longer exist for fp16 x MXFP4."""
 import ctypes as C
-import json
 import os
+import statistics
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-os.environ["PETIT_AMD_NO_TUNED"] = "1"
+# --mode heuristic (default): the table is off, the formula heuristic answers.  --mode nearest: the table is on and an unseen shape takes the
+# kernel of the nearest tabulated shape (hal.h tuned_nearest) -- meaningful with --heldout only (a table shape would find its own row).
+MODE = sys.argv[sys.argv.index("--mode") + 1] if "--mode" in sys.argv else "heuristic"
+if MODE == "heuristic":
+    os.environ["PETIT_AMD_NO_TUNED"] = "1"
 sys.path.insert(0, str(ROOT / "petit-kernel_amd"))
+sys.path.insert(0, str(ROOT / "tools"))
 from petit_kernel import _lib  # noqa: E402
 
-import csv
+from build_table import HELDOUT  # noqa: E402
+from table_from_candidates import read  # noqa: E402
 
-worst, rows = [], 0
-cells = {}   # (dtype, fmt, shape, n, k, m) -> {solution: us}
-import gzip
-for f in sorted((ROOT / "profiles").glob("r*_sweeps.csv.gz")):
-    if not f.name.startswith("r01"):
-        continue  # the heuristic was fitted on the r01 sweeps; later rounds only add kernels the arch table selects
-    for r in csv.DictReader(gzip.open(f, "rt")):
-        if r["fmt"] == "dense16" or "native" in r.get("sweep", "") or "vs_dense" in r.get("sweep", ""):
-            continue
-        if r["dtype"] == "f16" and r["fmt"] == "mx":
-            continue  # timings of the round-1 hi / lo split kernels, which no longer exist (round 4: Fp16Mx, the kernels test the scale range)
-        key = (r["dtype"], r["fmt"], r["shape"], int(r["n"]), int(r["k"]), int(r["m"]))
-        cells.setdefault(key, {})[int(r["solution"], 16)] = float(r["us_median"])
-for (dtype, fmt, shape, n, k, m), ok in sorted(cells.items()):
-    at = _lib.CXX_DTYPE_BF16 if dtype == "bf16" else _lib.CXX_DTYPE_FP16
-    bt = _lib.CXX_DTYPE_FP4_E2M1 if fmt == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1
+data = Path(sys.argv[sys.argv.index("--data") + 1]) if "--data" in sys.argv else ROOT / "profiles" / "r04_table_candidates.csv.gz"
+best, cands = read(data)
+only_held = "--heldout" in sys.argv
+BUCKETS = [(1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 64), (65, 128), (129, 256), (257, 1 << 20)]
+rows, missing = [], []
+for (at, bt, klass, m, n, k), (bsid, bus) in sorted(best.items()):
+    if klass != 0 or ((n, k) in HELDOUT) != only_held:
+        continue
     hints = _lib.SolutionHints(at, bt, at, 0)
     pick = _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k)
-    best = min(ok.values())
-    rows += 1
-    if pick in ok:
-        worst.append((ok[pick] / best, f"{dtype}x{fmt}", shape, m, _lib.describe_solution(pick).split("  (")[0]))
+    fam = f"{'bf16' if at == _lib.CXX_DTYPE_BF16 else 'f16'}x{'nv' if bt == _lib.CXX_DTYPE_FP4_E2M1 else 'mx'}"
+    timed = cands[(at, bt, klass, m, n, k)]
+    if pick in timed:
+        rows.append((timed[pick] / bus, fam, n, k, m, _lib.describe_solution(pick).split("  (")[0], _lib.describe_solution(bsid).split("  (")[0]))
     else:
-        worst.append((float("nan"), f"{dtype}x{fmt}", shape, m, "not timed: " + _lib.describe_solution(pick).split("  (")[0]))
-timed = sorted(w for w in worst if w[0] == w[0])
-print(f"{rows} cases, {len(timed)} heuristic picks found in the sweeps")
-import statistics
-print(f"slowdown vs best: median {statistics.median(w[0] for w in timed):.3f}, p90 {timed[int(0.9 * len(timed))][0]:.3f}, max {timed[-1][0]:.3f}")
-for w in timed[-12:]:
-    print(f"  {w[0]:.2f}x  {w[1]:10s} {w[2]:8s} M={w[3]:<5d} {w[4]}")
-if "--by-m" in sys.argv:
-    by = {}
-    for w in timed:
-        by.setdefault(w[3], []).append(w[0])
-    for m in sorted(by):
-        v = sorted(by[m])
-        print(f"M={m:<5d} n={len(v):2d} median {statistics.median(v):.2f} max {v[-1]:.2f}")
+        missing.append((fam, n, k, m, _lib.describe_solution(pick).split("  (")[0]))
+rows.sort()
+print(f"mode {MODE}: {len(rows) + len(missing)} cases ({'held-out shapes' if only_held else 'table shapes'}), {len(rows)} picks found in the tuner's log")
+if rows:
+    print(f"slowdown vs best: median {statistics.median(r[0] for r in rows):.3f}, p90 {rows[int(0.9 * len(rows))][0]:.3f}, max {rows[-1][0]:.3f}")
+    for r in rows[-12:]:
+        print(f"  {r[0]:.2f}x  {r[1]:8s} {r[2]}x{r[3]} M={r[4]:<4d} {r[5]}   (best: {r[6]})")
+if missing:
+    print(f"{len(missing)} picks the tuner did not time (e.g. a kernel its output check rejected), first: {missing[0]}")
+if "--by-m" in sys.argv and rows:
+    print("| M bucket | cases | median | p90 | max |")
+    print("|---|---|---|---|---|")
+    for lo, hi in BUCKETS:
+        v = sorted(r[0] for r in rows if lo <= r[4] <= hi)
+        if v:
+            print(f"| {lo}-{hi if hi < 1 << 20 else ''} | {len(v)} | {statistics.median(v):.2f} | {v[int(0.9 * len(v))]:.2f} | {v[-1]:.2f} |")
