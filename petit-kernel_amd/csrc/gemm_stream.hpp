@@ -575,7 +575,14 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
             *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
         } else {
             float *slab = p.workspace + ((size_t)blockIdx.z * p.m + m) * p.n + n;
-            *reinterpret_cast<f32x4 *>(slab) = v;
+            if constexpr (kCombine) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                // write-through to memory (sc0 sc1): visible to the other XCDs without a write-back of this XCD's whole L2
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(slab), "v"(v) : "memory");
+#endif
+            } else {
+                *reinterpret_cast<f32x4 *>(slab) = v;
+            }
         }
     };
     // SiLU-mul: logical tiles (inn, inn + 1) are the gate / up halves of output tile ntile / 2 (host guarantees
@@ -655,16 +662,19 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
         // are not coherent with this one), then ONE thread takes the workgroup's ticket for this output tile; the workgroup that draws the
         // last ticket acquires, re-arms the counter for the next launch and sums the slabs in slice order.
         if (gridDim.z > 1) {
+            // (the slab stores above are write-through and the last arriver's loads below bypass the caches: no agent-scope fence, whose
+            //  L2 write-back / invalidate per workgroup measured 15-55 us per launch -- profiles/r04_ksplit_combine.json, first variant)
             __shared__ unsigned ticket;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __syncthreads();
             if (threadIdx.x == 0)
-                ticket = __hip_atomic_fetch_add(arg_tickets + (blockIdx.y * gridDim.x + block_x), 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = __hip_atomic_fetch_add(arg_tickets + (blockIdx.y * gridDim.x + block_x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             if (ticket == gridDim.z - 1) {
                 if (threadIdx.x == 0)
                     __hip_atomic_store(arg_tickets + (blockIdx.y * gridDim.x + block_x), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 for (unsigned item = threadIdx.x; item < (unsigned)Cfg::kRedItems; item += Cfg::kThreads) {
                     const unsigned tile = item >> 6, il = item & 63u;
                     const unsigned iwn = tile / (MT * NT), imt = (tile / NT) % MT, inn = tile % NT;
@@ -674,9 +684,14 @@ __device__ __forceinline__ void gemm_stream_body(const void *arg_w, const void *
                     if (m >= p.m || ntile >= ntiles)
                         continue;
                     const float *src = p.workspace + (size_t)m * p.n + n;
-                    f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src));
-                    for (unsigned z = 1; z < gridDim.z; ++z)
-                        v += __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src + (size_t)z * p.m * p.n));
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (unsigned z = 0; z < gridDim.z; ++z) {
+                        f32x4 part;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(part) : "v"(src + (size_t)z * p.m * p.n) : "memory");
+#endif
+                        v += part;
+                    }
                     *reinterpret_cast<uint2 *>((char *)p.c + ((size_t)m * p.n + n) * 2) = finish4<AT>(v, gs, p.bias, n);
                 }
             }

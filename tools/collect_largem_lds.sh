@@ -42,13 +42,14 @@ for tag in ("nv_wide128", "nv_wide128x256", "mx_wide64x256", "hipblaslt"):
         continue
     v = {k: statistics.median(x) for k, x in vals.items()}
     ns = statistics.median(dur)
-    cu_cycles = v["GRBM_GUI_ACTIVE"] * 256           # CU-cycles of the launch (LDS counters are per CU / per SQ)
+    gui = v["GRBM_GUI_ACTIVE"] / 8                   # the counter is summed over the 8 XCDs (tools/pmc_mfma_to_json.py)
+    cu_cycles = gui * 256                            # CU-cycles of the launch (SQ counters are summed over the chip)
     v.update({"kernel": name[:80], "kernel_us": ns / 1e3, "tflops": 2.0 * 512 * 57344 * 8192 / ns / 1e3,
               "lds_instr_per_mfma": v["SQ_INSTS_LDS"] / v["SQ_INSTS_MFMA"],
               "lds_idx_active_frac_of_cu_cycles": v.get("SQ_LDS_IDX_ACTIVE", 0) / cu_cycles,
               "lds_bank_conflict_frac_of_lds_cycles": v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1),
-              "mfma_busy_frac_of_simd_cycles": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] * 1024),
-              "effective_clock_ghz": v["GRBM_GUI_ACTIVE"] / ns})
+              "mfma_busy_frac_of_simd_cycles": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 1024),
+              "effective_clock_ghz": gui / ns})
     out[tag] = v
     print(tag, json.dumps({k: (round(x, 4) if isinstance(x, float) else x) for k, x in v.items()}))
 json.dump(out, open("$OUT/largem_lds.json", "w"), indent=1)

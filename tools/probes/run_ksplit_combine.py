@@ -25,7 +25,7 @@ dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(dev)
 out = []
 SHAPES = {0: "16x32 (NT 2)", 1: "16x64 (NT 4)", 2: "16x128 (WN 2 x NT 4)"}
-for name, (n, k) in (("o", (8192, 8192)), ("down", (8192, 28672)), ("qkv", (10240, 8192))):
+for name, (n, k) in (("o", (8192, 8192)), ("down", (8192, 28672))):
     w = BL.Weights("nv", n, k, 1280, dev)
     for m in (16, 8):
         g = BL.Gemm(w, m, torch.bfloat16, dev)
