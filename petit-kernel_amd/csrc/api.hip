@@ -149,7 +149,8 @@ void *registered_workspace(int dev, void *stream, uint64_t need, bool *busy) {
 // (The reference's heuristic ignores the CU count altogether and leaves half of
 // a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
 // SiLU-mul epilogue: a wave must hold the gate and the up tile of an output tile -> even n-tiles per wave
-bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0; }
+bool is_shared(const SolutionEntry &e) { return e.shape.am == kWideAm && e.shape.wm == 5; } // gemm_shared.hpp (plain / bias epilogue only)
+bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0 && !is_shared(e); }
 
 // M > 16: a cost model calibrated on the r01 sweeps (profiles/r01_tune_midm_*.json, r01_tune_bigm_*.json; microseconds
 // on MI355X, bf16 x NVFP4; the other families scale uniformly, which does not change the argmin much):
@@ -1078,6 +1079,12 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d%s d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, lw ? " +loader" : "", s.d,
                  s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * (s.wn * wm * kgrp + lw));
+        return kOk;
+    }
+    if (s.am == kWideAm && s.wm == 5) {
+        snprintf(buf, len, "shared32 %sx%s ks%d nb%d splitk%u  (wg tile %dx%d, 256 threads: 4 waves along M, W unpacked once into LDS, 32x32x16 mfma)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks, s.nt / 2, solution_splitk(id), 32 * s.mt,
+                 16 * s.nt);
         return kOk;
     }
     if (s.am == kWideAm) {

@@ -4,5 +4,6 @@
 #define PETIT_TU_TABLE solutions_mx_bf16
 #define PETIT_TU_NATIVE_AT Bf16
 #define PETIT_TU_QUANTIZE quantize32_bf16
+#define PETIT_TU_SHARED
 #define PETIT_TU_PART 4
 #include "stream_tu.inc"

@@ -4,5 +4,6 @@
 #define PETIT_TU_TABLE solutions_nv_bf16
 #define PETIT_TU_BFP_AT Bf16Bfp
 #define PETIT_TU_DECODE
+#define PETIT_TU_SHARED
 #define PETIT_TU_PART 4
 #include "stream_tu.inc"

@@ -3,5 +3,6 @@
 #define PETIT_TU_FMT kFmtNv
 #define PETIT_TU_TABLE solutions_nv_f16
 #define PETIT_TU_DECODE
+#define PETIT_TU_SHARED
 #define PETIT_TU_PART 4
 #include "stream_tu.inc"
