@@ -272,7 +272,8 @@ int petit_gemm_mxfp4_fp16_grid_ws(unsigned *c, const unsigned *a, const unsigned
 uint64_t petit_gemm_workspace_bytes(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
                                     uint64_t solution_id);
 /* The same with the epilogue of the call taken into account: PETIT_SOLUTION_AUTO resolves differently under
- * PETIT_ACTIVATION_SILU_MUL (only kernels that hold a gate / up tile pair per wave qualify, none of them K-split). */
+ * PETIT_ACTIVATION_SILU_MUL (unsplit, only kernels that hold a gate / up tile pair per wave qualify; with a cross-workgroup K
+ * split any kernel does -- the slabs hold the plain [m][n] product and the reduce pass applies SiLU-mul). */
 uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k,
                                        uint64_t solution_id, const petit_epilogue *epilogue);
 int petit_set_workspace(void *device_ptr, uint64_t bytes);

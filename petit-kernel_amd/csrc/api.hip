@@ -150,7 +150,13 @@ void *registered_workspace(int dev, void *stream, uint64_t need, bool *busy) {
 // a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
 // SiLU-mul epilogue: a wave must hold the gate and the up tile of an output tile -> even n-tiles per wave
 bool is_shared(const SolutionEntry &e) { return e.shape.am == kWideAm && e.shape.wm == 5; } // gemm_shared.hpp (plain / bias epilogue only)
+enum : unsigned { kNeedK32 = 1u, kNeedQuantOut = 2u }; // restrictions of the native pipeline (entry_allows)
 bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0 && !is_shared(e); }
+// SiLU-mul with this (kernel, K split): unsplit, the kernel's own epilogue does it (gate and up tile in one wave: act_ok); with a cross-workgroup
+// K split the slabs hold the plain product and the REDUCE pass applies it (splitk_reduce_silu_kernel) -- any kernel, but a 16-bit output only
+bool act_runs(const SolutionEntry &e, unsigned splitk, unsigned restrict_ = 0) {
+    return splitk > 1 ? !(restrict_ & kNeedQuantOut) : act_ok(e);
+}
 
 // M > 16: a cost model calibrated on the r01 sweeps (profiles/r01_tune_midm_*.json, r01_tune_bigm_*.json; microseconds
 // on MI355X, bf16 x NVFP4; the other families scale uniformly, which does not change the argmin much):
@@ -252,7 +258,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
             unsigned sk = 1;
             if (s.am == kTiledAm || s.am == kWideAm) {
                 us = tiled_cost_us(e, m, n, k, arch.num_cus);
-                if (splitk_out && !need_pairs) { // K-heavy / narrow problems leave most CUs idle without a K split
+                if (splitk_out) { // (SiLU-mul too: the reduce pass applies it) K-heavy / narrow problems leave most CUs idle without a K split
                     for (unsigned cand = 2; cand <= 8 && cand <= nspans; cand *= 2) {
                         const double c = tiled_cost_us(e, m, n, k, arch.num_cus, cand);
                         if (c < us)
@@ -392,7 +398,6 @@ int entry_class(const SolutionEntry &e) {
 }
 // restrictions the native pipeline puts on the kernel: bit 0 = pre-quantised activations (the 32x32x64 kernels' layout: kind 13
 // only), bit 1 = quantising SiLU-mul epilogue (kind 13 with 128 x 256 workgroup tiles, four waves, no K split)
-enum : unsigned { kNeedK32 = 1u, kNeedQuantOut = 2u };
 bool entry_allows(const SolutionEntry &e, unsigned restrict_) {
     const StreamShape &s = e.shape;
     if ((restrict_ & (kNeedK32 | kNeedQuantOut)) && s.am != kNative32Am)
@@ -426,7 +431,7 @@ const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, 
         const double wgs = (double)((m + bm - 1) / bm) * (double)((n + bn - 1) / bn);
         const double slots = (double)arch.num_cus * (two ? 2 : 1);
         for (unsigned sk = 1; sk <= 4 && sk <= nspans; sk *= 2) {
-            if (sk > 1 && (!have_slabs || need_pairs || (restrict_ & kNeedQuantOut)))
+            if (sk > 1 && (!have_slabs || (restrict_ & kNeedQuantOut)))
                 break;
             const double rounds = (double)(unsigned long)((wgs * sk + slots - 1) / slots);
             const double t_wg = 2.0 * bm * bn * ((double)k / sk) / (tflops * 1e6 / slots); // us: the workgroup's share of the chip rate
@@ -476,7 +481,7 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
         c.entry = find_entry(fam, tuned);
         c.splitk = solution_splitk(tuned);
         if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 ||
-                        (act && (!act_ok(*c.entry) || c.splitk != 1)) || !entry_allows(*c.entry, restrict_)))
+                        (act && !act_runs(*c.entry, c.splitk, restrict_)) || !entry_allows(*c.entry, restrict_)))
             c.entry = nullptr;
     }
     if (!c.entry && !nearest_disabled()) {
@@ -487,7 +492,7 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
             c.splitk = solution_splitk(near);
             const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
             if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 || c.splitk > nspans ||
-                            (act && (!act_ok(*c.entry) || c.splitk != 1)) || !entry_allows(*c.entry, restrict_)))
+                            (act && !act_runs(*c.entry, c.splitk, restrict_)) || !entry_allows(*c.entry, restrict_)))
                 c.entry = nullptr;
         }
     }
@@ -654,8 +659,8 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         splitk = solution_splitk(solution_id);
         if (splitk == 0)
             return kErrKernelShape;
-        if (act && (!act_ok(*entry) || splitk != 1))
-            return kErrKernelShape; // needs an even number of n-tiles per wave and no cross-workgroup K split
+        if (act && !act_runs(*entry, splitk, restrict_))
+            return kErrKernelShape; // unsplit: needs an even number of n-tiles per wave; split: a 16-bit output (the reduce pass applies SiLU-mul)
         if (!entry_allows(*entry, restrict_) || (a_format && (unsigned)entry_class(*entry) != a_format))
             return kErrKernelShape;
     }
@@ -664,7 +669,6 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
     args.m = m, args.n = n, args.k = k;
     args.bias = epilogue ? epilogue->bias : nullptr;
-    args.act = act ? 1u : 0u;
     args.qa = a_format ? (const void *)a : nullptr, args.qa_format = a_format, args.out_format = out_format;
     const bool have_qa = a_format != 0;
     uint64_t need = workspace_need(*entry, splitk, m, n, k, have_qa);
@@ -708,7 +712,23 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         }
         args.workspace = (float *)ws;
     }
-    return entry->launch(args, splitk, (hipStream_t)stream);
+    // SiLU-mul: in the kernel's epilogue unsplit; by the reduce pass over plain slabs with a cross-workgroup K split
+    args.act = (act && splitk == 1) ? 1u : 0u;
+    args.reduce_act = (act && splitk > 1) ? 1u : 0u;
+    int rc = entry->launch(args, splitk, (hipStream_t)stream);
+    if (rc == kErrSplitCollapsed) {
+        // K is too short for the split the id (or the table row) names: the kernel runs as one part, so SiLU-mul is its own epilogue's job
+        if (!act_ok(*entry)) {
+            if (!is_auto || klass != kClassExact)
+                return kErrKernelShape;
+            entry = heuristic(fam, m, n, k, true);
+            if (!entry || workspace_need(*entry, 1, m, n, k))
+                return kErrKernelShape;
+        }
+        args.act = 1u, args.reduce_act = 0u;
+        rc = entry->launch(args, 1, (hipStream_t)stream);
+    }
+    return rc;
 }
 
 } // namespace petit_amd
@@ -936,7 +956,7 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
     if (!is_auto_id(solution_id)) {
         const SolutionEntry *e = find_explicit(fam, solution_id);
         const unsigned sk = solution_splitk(solution_id);
-        if (!e || !sk || !entry_fits(*e, m, k) || (act && (!act_ok(*e) || sk != 1)) || workspace_need(*e, sk, m, n, k) > workspace_bytes)
+        if (!e || !sk || !entry_fits(*e, m, k) || (act && !act_runs(*e, sk)) || workspace_need(*e, sk, m, n, k) > workspace_bytes)
             return 0;
         return make_solution_id(e->shape, fam.elem_b, entry_mfma(fam, *e), sk);
     }

@@ -291,12 +291,14 @@ struct Native32Cfg {
     // fragments ONE m-block ahead instead (kLean: 18 registers; an FP8-rate MFMA pair covers the LDS latency), which is what lets the
     // 128 x 256 tile fit two workgroups per CU for MXFP8 activations too
     static constexpr bool kLean = ACT == 8 && WM == 1 && KG == 1 && LW_ == 0 && MB * NP == 8 && D == 2;
-    static constexpr int kMinWavesPerSimd = (KG == 2 || kLean || (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2)) ? 2 : 1;
+    static constexpr bool kWantTwoPerSimd = KG == 2 || kLean || (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2);
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
     static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;       // KG = 2: the second group's accumulators, f32
     static constexpr int kSmemU4a = KG * NBUF * kStageU4 > kCTileU4 ? KG * NBUF * kStageU4 : kCTileU4;
     static constexpr int kSmemU4 = (kSmemU4a > kRedU4 ? kSmemU4a : kRedU4) + 16 * PW;
     static_assert(kSmemU4 * 16 <= 160 * 1024, "LDS budget");
+    // (a register budget for two workgroups per CU only where their LDS fits twice as well)
+    static constexpr int kMinWavesPerSimd = (kWantTwoPerSimd && (KG == 2 || kSmemU4 * 16 <= 80 * 1024)) ? 2 : 1;
 };
 
 // W refills (wave-loads) the stage that starts at tile t_first of a span issues: the tiles whose slot is needed again

@@ -757,4 +757,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(void *c, const float
     }
 }
 
+// The same second pass with the SiLU-mul epilogue: the slabs hold the plain [m][n] product (the kernels ran with act = 0), the output is
+// [m][n / 2], c[r][j] = silu(y[r][j]) * y[r][j + n/2] with y = sum * gs + bias -- the arithmetic of finish4_silu_mul, one rounding.
+template <class AT>
+__global__ __launch_bounds__(256) void splitk_reduce_silu_kernel(void *c, const float *ws, const float *gs_ptr, const void *bias,
+                                                                 unsigned m, unsigned n, unsigned parts) {
+    const unsigned n_half = n >> 1, q_per_row = n_half / 4;
+    const size_t total4 = (size_t)m * q_per_row;
+    const float gs = *gs_ptr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned row = (unsigned)(i / q_per_row), col = (unsigned)(i % q_per_row) * 4;
+        const float *const src = ws + (size_t)row * n + col;
+        f32x4 gate = *reinterpret_cast<const f32x4 *>(src), up = *reinterpret_cast<const f32x4 *>(src + n_half);
+        for (unsigned q = 1; q < parts; ++q) {
+            gate += *reinterpret_cast<const f32x4 *>(src + (size_t)q * m * n);
+            up += *reinterpret_cast<const f32x4 *>(src + (size_t)q * m * n + n_half);
+        }
+        reinterpret_cast<uint2 *>(c)[i] = finish4_silu_mul<AT>(gate, up, gs, bias, col, n_half);
+    }
+}
+
 } // namespace petit_amd

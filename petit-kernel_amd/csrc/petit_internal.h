@@ -16,6 +16,9 @@ enum : int {
     kErrKernelShape = 2,  // kErrorKernelShape
     kErrLaunch = 3,       // hipGetLastError() != hipSuccess after a launch
     kErrBadArgument = 4,  // null pointer / unknown dtype
+    // internal, never returned to a caller: a launcher asked for SiLU-mul in the reduce pass found that the K range does not split (fewer
+    // spans than parts -> one part, no reduce pass); gemm_impl then runs the kernel unsplit with SiLU-mul in its own epilogue
+    kErrSplitCollapsed = 100,
 };
 
 // Arithmetic / element types, numbered as the reference's C++ DataType
@@ -45,6 +48,7 @@ struct GemmArgs {
     const float *gs;    // device pointer, one float
     const void *bias;   // optional fused epilogue: [n] in c's dtype, added before the single rounding; may be null
     unsigned act;       // 0 none; 1 SiLU-mul: c is [m][n/2], c[m][j] = silu(y[m][j]) * y[m][j + n/2]  (y = acc*gs + bias)
+    unsigned reduce_act; // 1: SiLU-mul with a cross-workgroup K split -- the kernels see act = 0 (plain slabs), the reduce pass applies it
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
     unsigned m, n, k;
     unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))

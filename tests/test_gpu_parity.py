@@ -820,6 +820,26 @@ def test_fused_silu_mul_epilogue(pk, kind, is_bf16, with_bias, m, n, k):
         assert (err <= np.maximum(1e-2, 2e-2 * np.abs(ref))).all(), f"sid {sid:#x}: max err {err.max()}"
         served += 1
     assert served >= 2
+    # with a cross-workgroup K split the reduce pass applies SiLU-mul over plain slabs: every kernel serves it then, the ones above that
+    # refuse it unsplit included (odd n-tiles per wave, the LDS-shared kernel)
+    split_served = 0
+    for sid in pk.ops.get_fp4_solutions(h, m, n, k):
+        ks = ((sid >> 16) & 0x1F) // 2                        # k-tiles per span: a split needs a span per part
+        kind_nib = (sid >> 48) & 0xF
+        if kind_nib in (9, 13) or k // (128 * ks) < 2:        # (the native class has its own accuracy bound: test_native_*)
+            continue
+        sid2 = (sid & ~(0xF << 60)) | (2 << 60)
+        try:
+            plain = mul(ad, b, sp, gsd, m, n, k, sid2)        # does this kernel take a 2-way split of this K at all?
+        except RuntimeError:
+            continue
+        del plain
+        c = mul(ad, b, sp, gsd, m, n, k, sid2, bias=bd, activation="silu_mul")
+        assert c.shape == (m, n // 2) and c.dtype == dtype
+        err = np.abs(to_f32(bits(c), is_bf16).astype(np.float64) - ref)
+        assert (err <= np.maximum(1e-2, 2e-2 * np.abs(ref))).all(), f"sid {sid2:#x}: max err {err.max()}"
+        split_served += 1
+    assert split_served >= 2 or k < 2048
 
 
 # --- adversarial activations: the kernels must not depend on the activations' dynamic range ---------------
