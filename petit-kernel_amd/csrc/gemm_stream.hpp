@@ -750,9 +750,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(void *c, const float
     const float gs = *gs_ptr;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 v = reinterpret_cast<const f32x4 *>(ws)[i];
-        for (unsigned q = 1; q < parts; ++q)
-            v += reinterpret_cast<const f32x4 *>(ws + (size_t)q * m * n)[i];
+        // (the slabs of a batch are requested together -- a runtime-length loop of dependent adds would wait out one L2 / MALL round trip per
+        //  slab -- and summed in slab order, the fixed order of the plain loop)
+        const f32x4 *const src = reinterpret_cast<const f32x4 *>(ws) + i;
+        const size_t slab4 = (size_t)m * n / 4;
+        f32x4 v = src[0];
+        unsigned q = 1;
+        for (; q + 3 < parts; q += 4) {
+            const f32x4 x0 = src[(size_t)q * slab4], x1 = src[(size_t)(q + 1) * slab4], x2 = src[(size_t)(q + 2) * slab4], x3 = src[(size_t)(q + 3) * slab4];
+            v += x0, v += x1, v += x2, v += x3;
+        }
+        for (; q < parts; ++q)
+            v += src[(size_t)q * slab4];
         reinterpret_cast<uint2 *>(c)[i] = finish4<AT>(v, gs, bias, (unsigned)((i * 4) % n));
     }
 }
@@ -770,9 +779,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_silu_kernel(void *c, const 
         const unsigned row = (unsigned)(i / q_per_row), col = (unsigned)(i % q_per_row) * 4;
         const float *const src = ws + (size_t)row * n + col;
         f32x4 gate = *reinterpret_cast<const f32x4 *>(src), up = *reinterpret_cast<const f32x4 *>(src + n_half);
-        for (unsigned q = 1; q < parts; ++q) {
-            gate += *reinterpret_cast<const f32x4 *>(src + (size_t)q * m * n);
-            up += *reinterpret_cast<const f32x4 *>(src + (size_t)q * m * n + n_half);
+        const size_t slab = (size_t)m * n;
+        unsigned q = 1;
+        for (; q + 1 < parts; q += 2) { // (two slabs requested together, summed in slab order)
+            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(src + q * slab), u0 = *reinterpret_cast<const f32x4 *>(src + q * slab + n_half);
+            const f32x4 g1 = *reinterpret_cast<const f32x4 *>(src + (q + 1) * slab), u1 = *reinterpret_cast<const f32x4 *>(src + (q + 1) * slab + n_half);
+            gate += g0, gate += g1, up += u0, up += u1;
+        }
+        for (; q < parts; ++q) {
+            gate += *reinterpret_cast<const f32x4 *>(src + q * slab);
+            up += *reinterpret_cast<const f32x4 *>(src + q * slab + n_half);
         }
         reinterpret_cast<uint2 *>(c)[i] = finish4_silu_mul<AT>(gate, up, gs, bias, col, n_half);
     }
