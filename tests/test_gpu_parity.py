@@ -277,6 +277,26 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
+# shapes NO table knows, each within reach of a tabulated one (api.hip kNearestMaxDistance): solution_id = -1 runs the kernel the arch table names
+# for the NEAREST tabulated shape (hal.hip tuned_nearest) -- kernels picked for another N / K, K splits sized for another span count, 224- and
+# 320-column tiles on an N they do not divide
+UNSEEN_SHAPES = [(1, 5152, 5120), (8, 7232, 2304), (16, 4192, 13312), (24, 8160, 7936), (32, 10400, 8704), (48, 3616, 4352), (64, 8192, 7168),
+                 (96, 2496, 7424), (128, 6176, 3840), (200, 14560, 5120), (256, 28704, 4096), (384, 4160, 4864), (512, 7200, 8192)]
+
+
+@pytest.mark.parametrize("m,n,k", UNSEEN_SHAPES)
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
+def test_default_solution_on_unseen_shapes_near_the_table(pk, kind, is_bf16, m, n, k):
+    from petit_kernel import _lib
+    import ctypes as C
+    dt = _lib.CXX_DTYPE_BF16 if is_bf16 else _lib.CXX_DTYPE_FP16
+    hints = _lib.SolutionHints(dt, _lib.CXX_DTYPE_FP4_E2M1 if kind == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1, dt, 0)
+    assert _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k) != 0
+    a, q, s, gs = random_problem(kind, m, n, k, 77 + m + n + k, is_bf16)
+    c = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k)
+    check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+
+
 MX_F16_PROBLEMS = [(1, 256, 2048), (3, 96, 512), (8, 160, 1024), (16, 288, 1024), (40, 64, 3072), (64, 128, 2048), (130, 256, 1024), (300, 512, 768),
                    (2, 4128, 4096), (512, 1024, 2048), (16, 512, 8192), (256, 256, 4096)]
 
