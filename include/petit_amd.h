@@ -77,12 +77,13 @@ typedef struct petit_solution_hints {
  * fp4/gemm_fp4_fp16_grid.cc:46-48. */
 #define PETIT_SOLUTION_AUTO UINT64_MAX
 /* "Let the library choose INSIDE the native-FP4 class" (MXFP4 entry points only; see "Native-FP4 kernels" below): the caller
- * opts into quantised activations by naming the sentinel -- MXFP8 activations (FP4 x FP8 block-scaled MFMA) or MXFP4
- * activations (FP4 x FP4).  Needs per-call scratch (petit_gemm_workspace_bytes with the same sentinel); without it the call
+ * opts into quantised activations by naming the sentinel -- MXFP8 activations (FP4 x FP8 block-scaled MFMA), MXFP6 (e2m3
+ * elements: the three mantissa bits of e4m3 at the instruction's FP4 rate) or MXFP4 activations (FP4 x FP4).  Needs per-call scratch (petit_gemm_workspace_bytes with the same sentinel); without it the call
  * returns PETIT_ERROR_KERNEL_SHAPE rather than silently running another accuracy class.  The Python layers spell them
- * solution_id = -2 / -3. */
+ * solution_id = -2 / -3 / -4. */
 #define PETIT_SOLUTION_AUTO_NATIVE_MXFP8 (UINT64_MAX - 1)
 #define PETIT_SOLUTION_AUTO_NATIVE_MXFP4 (UINT64_MAX - 2)
+#define PETIT_SOLUTION_AUTO_NATIVE_MXFP6 (UINT64_MAX - 3)
 
 /*
  * c[m][n] = a[m][k] . dequant(b)[n][k]^T * (*global_scale), f32 accumulate,
@@ -305,15 +306,15 @@ uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);
  *              16-bit [m][n/2] matrix: gate_up -> SiLU-mul -> down of a gated MLP in two launches.  Needs n % 512 == 0 and a
  *              kernel with 128 x 256 workgroup tiles (the sentinels pick one).  Quantised from the f32 result with the
  *              quantiser's own rule (E8M0 scale from the block maximum of 32 columns).
- * solution_id: PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4 (must match a_format when given) or an explicit native kernel id;
+ * solution_id: PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP6 / _MXFP4 (must match a_format when given) or an explicit native kernel id;
  * with a_format or out_format set only the 32x32x64 kernels qualify (PETIT_ERROR_KERNEL_SHAPE otherwise).  hints->a_type
  * names the 16-bit type of the matrix input / output and of the bias.  workspace: what petit_gemm_native_workspace_bytes()
  * says for the same arguments (with a_format set: only the slabs of a K split; often 0).
  */
 typedef struct petit_native_args {
     uint32_t struct_bytes; /* sizeof(petit_native_args) */
-    int32_t a_format;      /* 0, 8 (MXFP8) or 4 (MXFP4) */
-    int32_t out_format;    /* 0, 8 or 4 */
+    int32_t a_format;      /* 0, 8 (MXFP8), 6 (MXFP6 e2m3) or 4 (MXFP4) */
+    int32_t out_format;    /* 0, 8, 6 or 4 */
     int32_t reserved;      /* 0 */
 } petit_native_args;
 int petit_gemm_mxfp4_native(void *c, const void *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,

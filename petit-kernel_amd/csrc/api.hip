@@ -358,6 +358,8 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
 unsigned entry_mfma(const Family &fam, const SolutionEntry &e) {
     if (e.shape.am == kNative32Am && e.shape.pa == 2) // activations quantised to MXFP4
         return e.a_type == kDataTypeFp16 ? kMfmaFp4ActFp16 : kMfmaFp4;
+    if (e.shape.am == kNative32Am && e.shape.pa == 4) // activations quantised to MXFP6
+        return e.a_type == kDataTypeFp16 ? kMfmaFp6ActFp16 : kMfmaFp6;
     if (is_native_am(e.shape.am))
         return e.a_type == kDataTypeFp16 ? kMfmaFp8ActFp16 : kMfmaFp8;
     return fam.mfma;
@@ -390,10 +392,12 @@ bool native_enabled() {
 // the two sentinels: arch table of the class first (tuned_native_gfx950.inc / tune-file rows that name a native kernel), else a
 // small model: rounds the grid needs on the chip x time of one workgroup at the throughput its tile shape sustained on MI355X
 // (bench cells of rounds 2-3: FP4 x FP4 128x256 with two workgroups per CU 3.3 PFLOP/s, 128x128 2.5; FP4 x FP8 64x256 2.3).
-enum : int { kClassExact = 0, kClassNativeFp8 = 8, kClassNativeFp4 = 4 };
+enum : int { kClassExact = 0, kClassNativeFp8 = 8, kClassNativeFp6 = 6, kClassNativeFp4 = 4 };
 int entry_class(const SolutionEntry &e) {
     if (!is_native_am(e.shape.am))
         return kClassExact;
+    if (e.shape.am == kNative32Am && e.shape.pa == 4)
+        return kClassNativeFp6;
     return (e.shape.am == kNative32Am && e.shape.pa == 2) ? kClassNativeFp4 : kClassNativeFp8;
 }
 // restrictions the native pipeline puts on the kernel: bit 0 = pre-quantised activations (the 32x32x64 kernels' layout: kind 13
@@ -420,9 +424,10 @@ const SolutionEntry *heuristic_native(const Family &fam, int klass, unsigned m, 
             continue; // (wm = 2: two waves along M, a measured loser kept as a tested instance; wm = 3: two K groups)
         const bool k32 = s.am == kNative32Am;
         const unsigned bm = (k32 ? 32u : 16u) * s.mt, bn = 16u * s.wn * s.nt;
-        const bool two = k32 && klass == kClassNativeFp4 && s.mt * s.nt == 16 && s.d == 2; // Native32Cfg::kMinWavesPerSimd
+        const bool fp4_rate = klass == kClassNativeFp4 || klass == kClassNativeFp6; // (e2m3 activations run at the e2m1 rate)
+        const bool two = k32 && fp4_rate && s.mt * s.nt == 16 && s.d == 2; // Native32Cfg::kMinWavesPerSimd
         double tflops; // sustained by this tile shape when the chip is full
-        if (k32 && klass == kClassNativeFp4)
+        if (k32 && fp4_rate)
             tflops = two ? 3300.0 : (s.mt * s.nt == 16 ? 2300.0 : 2500.0) + 50.0 * ((s.wk / 4 == 2) + (s.wk % 4 == 2)) + (s.wm == 3 ? 300.0 : 0.0);
         else if (k32)
             tflops = 2000.0;
@@ -503,7 +508,10 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
     return c;
 }
 int auto_class(uint64_t solution_id) {
-    return solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP8 ? kClassNativeFp8 : solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP4 ? kClassNativeFp4 : kClassExact;
+    return solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP8   ? kClassNativeFp8
+           : solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP6 ? kClassNativeFp6
+           : solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP4 ? kClassNativeFp4
+                                                             : kClassExact;
 }
 bool is_auto_id(uint64_t solution_id) { return solution_id == PETIT_SOLUTION_AUTO || auto_class(solution_id) != kClassExact; }
 
@@ -589,7 +597,7 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         return kErrBadArgument; // reject what a newer caller might ask for
     const bool act = epilogue && epilogue->activation == PETIT_ACTIVATION_SILU_MUL;
     const unsigned a_format = io ? io->a_format : 0u, out_format = io ? io->out_format : 0u;
-    if ((a_format != 0 && a_format != 8 && a_format != 4) || (out_format != 0 && out_format != 8 && out_format != 4))
+    if ((a_format != 0 && a_format != 8 && a_format != 6 && a_format != 4) || (out_format != 0 && out_format != 8 && out_format != 6 && out_format != 4))
         return kErrBadArgument;
     if (m == 0 || n == 0 || k == 0)
         return kOk; // gemm_fp4_fp16_grid.cc:42-44
@@ -812,7 +820,8 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
 
 static bool native_args_ok(const petit_native_args *na) {
     return !na || (na->struct_bytes == sizeof(petit_native_args) && na->reserved == 0 &&
-                   (na->a_format == 0 || na->a_format == 8 || na->a_format == 4) && (na->out_format == 0 || na->out_format == 8 || na->out_format == 4));
+                   (na->a_format == 0 || na->a_format == 8 || na->a_format == 6 || na->a_format == 4) &&
+                   (na->out_format == 0 || na->out_format == 8 || na->out_format == 6 || na->out_format == 4));
 }
 
 int petit_gemm_mxfp4_native(void *c, const void *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,
@@ -894,7 +903,7 @@ int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned coun
 }
 
 uint64_t petit_quantized_activation_bytes(unsigned m, unsigned k, int format) {
-    return format == 8 ? native32_ws_bytes<8>(m, k) : format == 4 ? native32_ws_bytes<4>(m, k) : 0;
+    return format == 8 ? native32_ws_bytes<8>(m, k) : format == 6 ? native32_ws_bytes<6>(m, k) : format == 4 ? native32_ws_bytes<4>(m, k) : 0;
 }
 
 int petit_quantize_activations(void *qa, const void *a, unsigned m, unsigned k, int a_type, int format, void *stream) {
@@ -1079,7 +1088,7 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     if (!buf || len == 0)
         return kErrBadArgument;
     const unsigned elem_b = (unsigned)(id >> 28) & 0xf, mfma = (unsigned)(id >> 32) & 0xf;
-    const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8 || mfma == kMfmaFp4) ? kDataTypeBf16 : kDataTypeFp16;
+    const int a_type = (mfma == kMfmaBf16 || mfma == kMfmaFp8 || mfma == kMfmaFp4 || mfma == kMfmaFp6) ? kDataTypeBf16 : kDataTypeFp16;
     const int b_type = (elem_b == kElemBMxFp4 || elem_b == 3u) ? kDataTypeMxFp4e2m1 : kDataTypeFp4e2m1; // (3: round 3's fp16-range nibble)
     Family fam;
     const SolutionEntry *e = family_for(a_type, b_type, &fam) ? find_explicit(fam, id) : nullptr;
@@ -1097,7 +1106,7 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     if (s.am == kNative32Am) {
         const int wm = s.wm == 2 ? 2 : 1, kgrp = s.wm == 3 ? 2 : 1, lw = s.wm == 4 ? 1 : 0;
         snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d%s d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, lw ? " +loader" : "", s.d,
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : s.pa == 4 ? "mxfp6" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, lw ? " +loader" : "", s.d,
                  s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * (s.wn * wm * kgrp + lw));
         return kOk;
     }

@@ -41,6 +41,11 @@ namespace petit_amd {
 //   ACT = 8: per 128-k tile 128 bytes in the order [0-15][32-47][16-31][48-63][64-79][96-111][80-95][112-127] (16-k units),
 //            so that lane (m, h) finds its P1 operand at byte 32h and its P2 operand at byte 64 + 32h.
 //   ACT = 4: per 128-k tile 64 bytes, natural nibble order: P1 operand at byte 16h, P2 at 32 + 16h.
+//   ACT = 6 (MXFP6, e2m3 elements: the instruction still runs at the FP4 rate, the elements carry e4m3's three mantissa bits): a 32-k block
+//            is 24 bytes = the 6 operand registers of one lane (element i at bits [6 i, 6 i + 6), tools/probes/mfma32_fp6_probe.hip).  Stored as
+//            TWO images so that every access stays a 16-byte one: qa_lo[K/128][M][64] holds registers 0-3 of block b at byte 16 b (the FP4
+//            geometry), qa_hi[K/128][M][32] registers 4-5 of blocks 0, 2, 1, 3 in that order (lane (m, h) reads ONE 16-byte unit h and finds
+//            the tail of its P1 block in the first 8 bytes, of its P2 block in the last 8); then the scales as above.
 template <int ACT> __host__ __device__ inline size_t native32_ws_bytes(unsigned m, unsigned k) {
     return (size_t)m * (k / 8 * ACT) + (size_t)m * (k / 32);
 }
@@ -123,6 +128,66 @@ __global__ __launch_bounds__(256) void quantize_act32_kernel(const void *a, unsi
         if (col16 == 0)
             *reinterpret_cast<unsigned *>(qs + ((size_t)kt * m + row) * 4) = sbyte | (s1 << 8) | (s2 << 16) | (s3 << 24);
     }
+}
+
+// MXFP6 (e2m3): one thread = one 32-k block of one row (the hardware converts 32 values at once: v_cvt_scalef32_pk32_fp6_{bf16,f16}, RNE of
+// src / scale, saturating at 7.5).  grid = (ceil(K / 32 / 256), M); the four blocks of a k-tile are four consecutive lanes.
+template <class AT>
+__global__ __launch_bounds__(256) void quantize_act32_fp6_kernel(const void *a, unsigned char *ws, unsigned m, unsigned k) {
+    const unsigned row = blockIdx.y, blocks = k / 32, blk = blockIdx.x * 256 + threadIdx.x;
+    if (blk >= blocks) // (K / 32 is a multiple of 4: the lanes of a k-tile leave together)
+        return;
+    unsigned char *const qa_lo = ws, *const qa_hi = ws + (size_t)m * (k / 2), *const qs = ws + (size_t)m * (k / 8 * 6);
+    const u32x4 *const src = reinterpret_cast<const u32x4 *>(a) + ((size_t)row * blocks + blk) * 4;
+    u32x4 raw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        raw[j] = src[j];
+    // block maximum on the 16-bit patterns (sign cleared: bf16 and fp16 magnitudes order like their bit patterns), exponent from its f32 value
+    unsigned mx = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned w = raw[j][d] & 0x7fff7fffu;
+            const unsigned lo = w & 0xffffu, hi = w >> 16;
+            mx = mx > lo ? mx : lo;
+            mx = mx > hi ? mx : hi;
+        }
+    float amax;
+    if constexpr (AT::kType == kDataTypeBf16) {
+        amax = __builtin_bit_cast(float, mx << 16);
+    } else {
+        const unsigned short hb = (unsigned short)mx;
+        amax = (float)__builtin_bit_cast(_Float16, hb);
+    }
+    // OCP MX scale 2^(E - emax_elem), emax_elem = 2 for e2m3 (largest normal 7.5 = 1.875 x 2^2): the maximum lands in [4, 8), above 7.5 saturates
+    const unsigned ebits = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;
+    unsigned sbyte = amax == 0.f ? 127u : (ebits > 2u ? ebits - 2u : 1u);
+    sbyte = sbyte > 254u ? 254u : sbyte;
+    const float scale = __builtin_bit_cast(float, sbyte << 23);
+    typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
+    typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
+    const u32x16 packed = u32x16{raw[0][0], raw[0][1], raw[0][2], raw[0][3], raw[1][0], raw[1][1], raw[1][2], raw[1][3],
+                                 raw[2][0], raw[2][1], raw[2][2], raw[2][3], raw[3][0], raw[3][1], raw[3][2], raw[3][3]};
+    u32x6 q;
+    if constexpr (AT::kType == kDataTypeBf16) {
+        typedef __attribute__((ext_vector_type(32))) __bf16 bf16x32;
+        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_bf16(__builtin_bit_cast(bf16x32, packed), scale);
+    } else {
+        typedef __attribute__((ext_vector_type(32))) _Float16 f16x32;
+        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, packed), scale);
+    }
+    const unsigned kt = blk / 4, b = blk % 4;
+    const size_t tile_row = (size_t)kt * m + row;
+    *reinterpret_cast<u32x4 *>(qa_lo + tile_row * 64 + 16 * b) = u32x4{q[0], q[1], q[2], q[3]};
+    uint2 tail;
+    tail.x = q[4], tail.y = q[5];
+    *reinterpret_cast<uint2 *>(qa_hi + tile_row * 32 + 8 * ((b & 1u) * 2 + (b >> 1))) = tail;
+    // the four scale bytes of a row's k-tile leave as one dword (the first lane of the four collects them)
+    const unsigned s1 = __shfl_down(sbyte, 1, 4), s2 = __shfl_down(sbyte, 2, 4), s3 = __shfl_down(sbyte, 3, 4);
+    if (b == 0)
+        *reinterpret_cast<unsigned *>(qs + tile_row * 4) = sbyte | (s1 << 8) | (s2 << 16) | (s3 << 24);
 }
 
 // The SiLU-mul epilogue as a PRODUCER of quantised activations (out_format 8 / 4; 128 x 256 workgroup tiles only: NP = 2, four waves).
@@ -246,7 +311,7 @@ struct Native32Cfg {
 #ifndef PETIT_N32_LWPF
 #define PETIT_N32_LWPF 0
 #endif
-    static constexpr int kLwStageLoads = KT_ * (32 * MB_ * WM_ * ACT_ / 64 + (32 * MB_ * WM_ + 63) / 64); // wave-loads of the loader per stage
+    static constexpr int kLwStageLoads = KT_ * (32 * MB_ * WM_ * ACT_ / 64 + (32 * MB_ * WM_ + 63) / 64); // wave-loads of the loader per stage (ACT = 4 / 8)
     static constexpr int kLwPfMax = 1 + 63 / kLwStageLoads;                                              // (vmcnt counts to 63)
     static constexpr int PF = (LW_ && PETIT_N32_LWPF) ? (PETIT_N32_LWPF < kLwPfMax ? PETIT_N32_LWPF : kLwPfMax) : PF_; // (experiment: deeper activation staging)
     static constexpr int KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, ACT = ACT_, KT = KT_, NBUF = PF + 1;
@@ -265,8 +330,10 @@ struct Native32Cfg {
     static_assert(KG == 1 || (KG == 2 && WM == 1), "two K groups only with one wave along M");
     static_assert(LW == 0 || (LW == 1 && KG == 1 && WM == 1 && PF_ >= 2), "the loader wave: one K group, stages in flight across the barrier");
     static constexpr int BM = 32 * MB * WM;
-    static constexpr int kRowU4 = ACT;                        // 16-byte units per LDS row: 128 B (FP8) / 64 B (FP4)
-    static constexpr int kDataU4 = BM * kRowU4;               // one tile image
+    static constexpr int kRowU4 = ACT == 6 ? 4 : ACT;         // 16-byte units per LDS row: 128 B (FP8) / 64 B (FP4; FP6: registers 0-3 of every block)
+    static constexpr int kLoU4 = BM * kRowU4;                 // FP6: the image of registers 0-3 ...
+    static constexpr int kHiU4 = ACT == 6 ? BM * 2 : 0;       // ... followed by the image of registers 4-5: 32 B per row
+    static constexpr int kDataU4 = kLoU4 + kHiU4;             // one tile image
     static constexpr int kScaleU4 = (BM + 3) / 4 < kWaves * 16 ? kWaves * 16 : (BM + 3) / 4; // one dword per row (wave-loads of 64)
     static constexpr int kRowsPerLoad = 64 / kRowU4;          // rows one 1 KiB wave-load covers: 8 / 16
     // waves that stage the activation tile: all of them when they divide its wave-loads, else four (five-wave workgroups: 160- and 320-column
@@ -275,13 +342,15 @@ struct Native32Cfg {
     static constexpr int kDmaWaves = (BM / kRowsPerLoad) % kWaves == 0 ? kWaves : 4;
     static constexpr int kDumpU4 = kDmaWaves < kWaves ? 64 : 0;
     static constexpr int kDataLoads = BM / kRowsPerLoad / kDmaWaves;
-    static_assert(ACT == 8 || ACT == 4, "activations are quantised to MXFP8 or MXFP4");
+    static constexpr int kHiLoads = ACT == 6 ? BM / 32 / kDmaWaves : 0; // FP6: wave-loads of the 32-byte rows (32 rows each)
+    static_assert(ACT == 8 || ACT == 6 || ACT == 4, "activations are quantised to MXFP8, MXFP6 or MXFP4");
+    static_assert(ACT != 6 || (BM % (32 * kDmaWaves) == 0 && LW_ == 0), "MXFP6: 128-row tiles, no loader wave");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(WM == 1 || WM == 2, "one or two waves along M");
     static_assert(BM % (kRowsPerLoad * kDmaWaves) == 0 && BM <= 64 * kWaves, "A tile must split evenly over the staging waves");
     static_assert((kRowsPerLoad * kDmaWaves) % 16 == 0, "wave-loads must step by whole 16-row groups (swizzle term constant)");
     static constexpr int kStageU4 = KT * (kDataU4 + kScaleU4) + kDumpU4;   // one stage: KT tile images, then their KT scale arrays (+ dump slot)
-    static constexpr int kStageLoads = KT * (kDataLoads + 1);    // VMEM ops one wave issues per stage
+    static constexpr int kStageLoads = KT * (kDataLoads + kHiLoads + 1); // VMEM ops one wave issues per stage
     static_assert(KS % KT == 0 && (KT == 1 || KT == 2) && PF >= 1 && (PF <= 3 || LW_), "stage = 1 or 2 k-tiles, 1 to 3 stages ahead");
     static_assert(D % KT == 0, "the W ring is refilled a stage at a time");
     static constexpr int BN = 32 * NP * WAVES;
@@ -290,8 +359,8 @@ struct Native32Cfg {
     // MXFP8 fragments are twice the size (the group-ahead double buffer of MB fragments is 64 registers + scales): that form reads its
     // fragments ONE m-block ahead instead (kLean: 18 registers; an FP8-rate MFMA pair covers the LDS latency), which is what lets the
     // 128 x 256 tile fit two workgroups per CU for MXFP8 activations too
-    static constexpr bool kLean = ACT == 8 && WM == 1 && KG == 1 && LW_ == 0 && MB * NP == 8 && D == 2;
-    static constexpr bool kWantTwoPerSimd = KG == 2 || kLean || (WM == 1 && ACT == 4 && MB * NP == 8 && D == 2);
+    static constexpr bool kLean = (ACT == 8 || ACT == 6) && WM == 1 && KG == 1 && LW_ == 0 && MB * NP == 8 && D == 2;
+    static constexpr bool kWantTwoPerSimd = KG == 2 || kLean || (WM == 1 && (ACT == 4 || ACT == 6) && MB * NP == 8 && D == 2);
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
     static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;       // KG = 2: the second group's accumulators, f32
     static constexpr int kSmemU4a = KG * NBUF * kStageU4 > kCTileU4 ? KG * NBUF * kStageU4 : kCTileU4;
@@ -320,7 +389,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     constexpr unsigned kRecBytes = ScaleRec<kFmtMx, KS>::kBytes;
     constexpr int kRecDw = ScaleRec<kFmtMx, KS>::kDwords;
     constexpr unsigned kOob = 0x80000000u;
-    constexpr int kFragU4 = ACT == 8 ? 2 : 1; // 16-byte units of one activation operand
+    constexpr int kFragU4 = ACT == 4 ? 1 : 2; // 16-byte units of one activation operand (FP6: registers 0-3, and the unit that holds 4-5 of P1 and P2)
+    constexpr int kBlgp = ACT == 8 ? 0 : ACT == 6 ? 2 : 4; // the activation operand's format: e4m3 / e2m3 / e2m1
 
     // NBUF stages of [KT tile images][KT scale arrays]
     __shared__ u32x4 smem[Cfg::kSmemU4];
@@ -377,9 +447,11 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     }
     // quantised activations and their scales, k-tile major (see the layout note above): tile kt of this m-block starts at
     // (kt M + m0) rows of 16 ACT (data) / 4 (scales) bytes; the descriptors end with the data / scale region
-    constexpr unsigned kRowB = 16 * ACT;
+    constexpr unsigned kRowB = 16 * Cfg::kRowU4;
     const size_t qa_bytes = (size_t)p.m * (p.k / 8 * ACT), qs_bytes = (size_t)p.m * (p.k / 32);
-    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * kRowB, (unsigned)(qa_bytes - (size_t)m0 * kRowB));
+    const size_t lo_bytes = (size_t)p.m * (p.k / 8 * Cfg::kRowU4); // (FP6: the first image; else all of the data)
+    const __amdgpu_buffer_rsrc_t qa_rsrc = make_rsrc(ws + (size_t)m0 * kRowB, (unsigned)(lo_bytes - (size_t)m0 * kRowB));
+    const __amdgpu_buffer_rsrc_t qh_rsrc = make_rsrc(ws + lo_bytes + (size_t)m0 * 32, ACT == 6 ? (unsigned)(qa_bytes - lo_bytes - (size_t)m0 * 32) : 0u);
     const __amdgpu_buffer_rsrc_t qs_rsrc = make_rsrc(ws + qa_bytes + (size_t)m0 * 4, (unsigned)(qs_bytes - (size_t)m0 * 4));
     const unsigned qa_tile = p.m * kRowB, qs_tile = p.m * 4; // bytes from one k-tile to the next
 
@@ -391,6 +463,10 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     const bool dma_wave = kDmaWaves == kWaves || wave < (unsigned)kDmaWaves;
     const unsigned dma_row0 = wave * RPL + lane / U;
     auto swz = [](unsigned row) -> unsigned { return ACT == 8 ? (row >> 1) & 7u : (row >> 2) & 3u; };
+    // FP6 tail image: rows of two units; lane l of a wave-load -> row l / 2, position l % 2, which receives unit (l % 2) ^ (row / 8) % 2 (the 16 lanes of a
+    // ds_read_b128 group -- 16 rows, 512 bytes -- then cover the 256-byte bank window twice without meeting)
+    const unsigned hi_row0 = wave * 32 + (lane >> 1);
+    const unsigned hi_voff = (ACT == 6 && dma_wave) ? hi_row0 * 32 + (((lane & 1u) ^ ((hi_row0 >> 3) & 1u)) * 16) : kOob;
     const unsigned dma_voff = dma_wave ? dma_row0 * kRowB + (((lane % U) ^ swz(dma_row0)) * 16) : kOob;
     const unsigned qs_voff = (wave * 64 < (unsigned)Cfg::BM) ? (wave * 64 + lane) * 4 : kOob;
     auto dma_stage = [&](unsigned kt, unsigned buf) { // k-tiles kt .. kt + KT - 1 -> stage `buf`
@@ -404,6 +480,12 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             for (int i = 0; i < Cfg::kDataLoads; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(qa_rsrc, (__attribute__((address_space(3))) void *)(dma_wave ? data + (i * kDmaWaves + wave) * 64 : dump), 16,
                                                          dma_voff, i * (RPL * kDmaWaves) * kRowB + (kt + t) * qa_tile, 0, 0);
+            if constexpr (ACT == 6) {
+#pragma unroll
+                for (int i = 0; i < Cfg::kHiLoads; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(qh_rsrc, (__attribute__((address_space(3))) void *)(dma_wave ? data + Cfg::kLoU4 + (i * kDmaWaves + wave) * 64 : dump), 16,
+                                                             hi_voff, i * (32 * kDmaWaves) * 32 + (kt + t) * (p.m * 32), 0, 0);
+            }
             u32x4 *const sc = smem_g + buf * Cfg::kStageU4 + KT * Cfg::kDataU4 + t * Cfg::kScaleU4;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(qs_rsrc, (__attribute__((address_space(3))) void *)(sc + wave * 16), 4, qs_voff, (kt + t) * qs_tile, 0, 0);
         }
@@ -421,12 +503,19 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
         int s;
     };
     const unsigned my_swz = swz(m_l); // (32 mb is a multiple of every swizzle period)
+    const unsigned hi_swz = (m_l >> 3) & 1u;
     auto read_frag1 = [&](const u32x4 *a_cur, const unsigned char *sc_bytes, int q, int mb, Frag1 &f) {
         const unsigned row = (wm * MB + mb) * 32 + m_l;
+        if constexpr (ACT == 6) {
+            f.d[0] = a_cur[row * U + ((2 * q + h) ^ my_swz)];
+            if (q == 0) // (the tail unit serves both operands of the k-tile: P2's half waits in tail_keep)
+                f.d[1] = a_cur[Cfg::kLoU4 + row * 2 + (h ^ hi_swz)];
+        } else {
 #pragma unroll
-        for (int e = 0; e < kFragU4; ++e) {
-            const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
-            f.d[e] = a_cur[row * U + (unit ^ my_swz)];
+            for (int e = 0; e < kFragU4; ++e) {
+                const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
+                f.d[e] = a_cur[row * U + (unit ^ my_swz)];
+            }
         }
         f.s = (int)sc_bytes[row * 4 + 2 * q + h];
     };
@@ -434,10 +523,16 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const unsigned row = (wm * MB + mb) * 32 + m_l;
+            if constexpr (ACT == 6) {
+                f.d[mb][0] = a_cur[row * U + ((2 * q + h) ^ my_swz)];
+                if (q == 0) // (the tail unit serves both operands of the k-tile: read with P1's, handed on to P2's below)
+                    f.d[mb][1] = a_cur[Cfg::kLoU4 + row * 2 + (h ^ hi_swz)];
+            } else {
 #pragma unroll
-            for (int e = 0; e < kFragU4; ++e) {
-                const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
-                f.d[mb][e] = a_cur[row * U + (unit ^ my_swz)];
+                for (int e = 0; e < kFragU4; ++e) {
+                    const unsigned unit = ACT == 8 ? 4 * q + 2 * h + e : 2 * q + h;
+                    f.d[mb][e] = a_cur[row * U + (unit ^ my_swz)];
+                }
             }
             f.s[mb] = (int)sc_bytes[row * 4 + 2 * q + h]; // the block this lane's k belongs to: 2 q + h
         }
@@ -584,6 +679,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
             }
             Frags fr[Cfg::kLean ? 1 : 2];
             Frag1 f1[2];
+            unsigned tail_keep[MB][2]; // kLean, FP6: registers 4-5 of the P2 operands, read with P1's
             if constexpr (Cfg::kLean)
                 read_frag1(stage, stage_sc, 0, 0, f1[0]);
             else
@@ -625,10 +721,20 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                                 read_frag1(stage + nti * Cfg::kDataU4, stage_sc + nti * Cfg::kScaleU4 * 16, nq, nmb, f1[(li + 1) & 1]);
                             }
                             const u32x4 lo = f1[li & 1].d[0], hi = f1[li & 1].d[kFragU4 - 1];
-                            const i32x8 aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                            i32x8 aop;
+                            if constexpr (ACT == 6) {
+                                if constexpr (q == 0) {
+                                    tail_keep[mb][0] = hi[2], tail_keep[mb][1] = hi[3];
+                                    aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], 0, 0};
+                                } else {
+                                    aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)tail_keep[mb][0], (int)tail_keep[mb][1], 0, 0};
+                                }
+                            } else {
+                                aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                            }
 #pragma unroll
                             for (int np = 0; np < NP; ++np)
-                                acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, 0 /* B = FP8 e4m3 */,
+                                acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, kBlgp /* B = FP8 e4m3 / FP6 e2m3 */,
                                                                                               T % 4, (int)rec[np][q].d[T / 4], 0, f1[li & 1].s);
                         });
                     }
@@ -636,6 +742,11 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                     if constexpr (!Cfg::kLean && gi + 1 < 2 * KT && !(PETIT_ABLATE_N32 & 4)) {
                         constexpr int nti = (gi + 1) / 2, nq = (gi + 1) % 2;
                         read_frags(stage + nti * Cfg::kDataU4, stage_sc + nti * Cfg::kScaleU4 * 16, nq, fr[(gi + 1) & 1]);
+                        if constexpr (ACT == 6 && nq == 1) { // P2's fragments: the tail unit P1's read brought (fr[0] is always a P1 set, fr[1] a P2 set)
+#pragma unroll
+                            for (int mb = 0; mb < MB; ++mb)
+                                fr[1].d[mb][1] = fr[0].d[mb][1];
+                        }
                     }
 #pragma unroll
                     for (int mb = 0; mb < (Cfg::kLean ? 0 : MB); ++mb) {
@@ -644,6 +755,9 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                         if constexpr (ACT == 8) {
                             const u32x4 lo = fr[fi].d[mb][0], hi = fr[fi].d[mb][kFragU4 - 1];
                             aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                        } else if constexpr (ACT == 6) {
+                            const u32x4 lo = fr[fi].d[mb][0], tail = fr[fi].d[mb][1];
+                            aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)tail[2 * q], (int)tail[2 * q + 1], 0, 0};
                         } else {
                             const u32x4 lo = fr[fi].d[mb][0];
                             aop = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], 0, 0, 0, 0};
@@ -656,7 +770,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 #endif
                             } else {
                                 acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                                    wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, ACT == 8 ? 0 : 4 /* B = FP8 e4m3 / FP4 */, T % 4,
+                                    wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, kBlgp /* B = FP8 e4m3 / FP6 e2m3 / FP4 */, T % 4,
                                     (int)rec[np][q].d[T / 4], 0, fr[fi].s[mb]);
                             }
                         }

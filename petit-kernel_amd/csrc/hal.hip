@@ -165,7 +165,7 @@ int solution_class(uint64_t solution) {
     const unsigned kind = (unsigned)(solution >> 48) & 0xf, mfma = (unsigned)(solution >> 32) & 0x7;
     if (kind != 9 && kind != 13)
         return 0;
-    return mfma == 6 ? 4 : 8; // mfma_type nibble: 2 = MXFP8 activations, 6 = MXFP4 (solution.h)
+    return mfma == 6 ? 4 : mfma == 4 ? 6 : 8; // mfma_type nibble: 2 = MXFP8 activations, 4 = MXFP6, 6 = MXFP4 (solution.h)
 }
 
 uint64_t tuned_generation() { return g_generation.load(std::memory_order_acquire); }

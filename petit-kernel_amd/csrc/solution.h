@@ -51,7 +51,7 @@ namespace petit_amd {
 
 enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
 enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u }; // (3 was round 3's "MXFP4, scales promised in fp16's range": read as 2 now, find_explicit in api.hip)
-enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u, kMfmaFp4 = 6u, kMfmaFp4ActFp16 = 6u | 8u };
+enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u, kMfmaFp4 = 6u, kMfmaFp4ActFp16 = 6u | 8u, kMfmaFp6 = 4u, kMfmaFp6ActFp16 = 4u | 8u };
 
 struct StreamShape {
     int ks, mt, nt, wn, wk, d, am; // am == kTiledAm marks the tiled kernel

@@ -408,7 +408,7 @@ int petit_gemm_tune(unsigned *c, const unsigned *a, const float *global_scale, u
                     void *stream, uint64_t *best_solution, float *best_us) {
     if (!hints || !params || params->struct_bytes != sizeof(petit_tune_params) || hints->c_type != hints->a_type)
         return kErrBadArgument;
-    if (params->klass != 0 && params->klass != 8 && params->klass != 4)
+    if (params->klass != 0 && params->klass != 8 && params->klass != 6 && params->klass != 4)
         return kErrBadArgument;
     if (((uintptr_t)workspace & 255) || (!workspace && workspace_bytes))
         return kErrBadArgument;

@@ -15,7 +15,7 @@ import torch
 from . import compiled, offline, ops, tuning
 from .ops import QuantizedActivations, mul_fp4_a16_grouped, mul_mxfp4_native, quantize_activations
 from .tuning import tune, tune_tensors
-from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
+from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP6, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
 from ._lib import MXFP4_F16RANGE_SCALE_MAX, MXFP4_F16RANGE_SCALE_MIN
 
 # operator layer: the compiled torch.library binding when it is built and loads (csrc/torch_binding.cpp), else the
@@ -109,4 +109,5 @@ __all__ = [
     "SOLUTION_AUTO",
     "SOLUTION_AUTO_NATIVE_MXFP8",
     "SOLUTION_AUTO_NATIVE_MXFP4",
+    "SOLUTION_AUTO_NATIVE_MXFP6",
 ]

@@ -20,6 +20,7 @@ PETIT_ERROR_BAD_ARGUMENT = 4
 PETIT_SOLUTION_AUTO = 0xFFFFFFFFFFFFFFFF
 PETIT_SOLUTION_AUTO_NATIVE_MXFP8 = PETIT_SOLUTION_AUTO - 1   # Python surface: solution_id = -2
 PETIT_SOLUTION_AUTO_NATIVE_MXFP4 = PETIT_SOLUTION_AUTO - 2   # Python surface: solution_id = -3
+PETIT_SOLUTION_AUTO_NATIVE_MXFP6 = PETIT_SOLUTION_AUTO - 3   # Python surface: solution_id = -4
 
 # C++ DataType numbering of the reference (quantization/types.h:4-13)
 CXX_DTYPE_FP4_E2M1 = 3

@@ -149,6 +149,7 @@ _ACTIVATIONS = {None: 0, "none": 0, "silu_mul": 1}   # PETIT_ACTIVATION_* (inclu
 SOLUTION_AUTO = -1
 SOLUTION_AUTO_NATIVE_MXFP8 = -2
 SOLUTION_AUTO_NATIVE_MXFP4 = -3
+SOLUTION_AUTO_NATIVE_MXFP6 = -4
 
 
 def _c_solution_id(solution_id: int, native_ok: bool = False) -> int:
@@ -159,6 +160,8 @@ def _c_solution_id(solution_id: int, native_ok: bool = False) -> int:
         return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8
     if native_ok and solution_id == SOLUTION_AUTO_NATIVE_MXFP4:
         return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4
+    if native_ok and solution_id == SOLUTION_AUTO_NATIVE_MXFP6:
+        return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6
     return _lib.PETIT_SOLUTION_AUTO if solution_id < 0 else solution_id
 
 _ws_need_cache = {}
@@ -348,7 +351,7 @@ def set_workspace(buf) -> None:
 
 # --- the native class as a pipeline (include/petit_amd.h "The native class as a PIPELINE"; no counterpart in the reference) ---
 
-_QFORMATS = {"mxfp8": 8, "mxfp4": 4}
+_QFORMATS = {"mxfp8": 8, "mxfp6": 6, "mxfp4": 4}
 
 
 class QuantizedActivations:
@@ -365,7 +368,7 @@ class QuantizedActivations:
 
 def quantize_activations(A: torch.Tensor, fmt: str = "mxfp4") -> QuantizedActivations:
     """16-bit activations [m, k] -> QuantizedActivations (one launch; share the result among GEMMs with the same input)."""
-    _check(fmt in _QFORMATS, "fmt must be 'mxfp8' or 'mxfp4'")
+    _check(fmt in _QFORMATS, "fmt must be 'mxfp8', 'mxfp6' or 'mxfp4'")
     _check(A.is_cuda and A.is_contiguous() and A.dim() == 2 and A.dtype in (torch.bfloat16, torch.float16),
            "A must be a contiguous 2-D bfloat16 / float16 GPU tensor")
     m, k = A.shape
@@ -398,7 +401,7 @@ def mul_mxfp4_native(A, B, s, global_scale, size_m, size_n, size_k, solution_id=
     _check(B.is_contiguous() and B.numel() * B.element_size() == size_n * size_k // 2, "B does not hold size_n * size_k packed 4-bit weights")
     _check(s.is_contiguous() and s.numel() * s.element_size() == size_n * size_k // 32, "s does not hold size_n * size_k / 32 scales")
     _check(activation in _ACTIVATIONS, f"activation must be one of {sorted(k for k in _ACTIVATIONS if k)} or None")
-    _check(out_quantized is None or out_quantized in _QFORMATS, "out_quantized must be None, 'mxfp8' or 'mxfp4'")
+    _check(out_quantized is None or out_quantized in _QFORMATS, "out_quantized must be None, 'mxfp8', 'mxfp6' or 'mxfp4'")
     act = _ACTIVATIONS[activation]
     out_fmt = _QFORMATS[out_quantized] if out_quantized else 0
     _check(not out_fmt or act, "out_quantized needs activation='silu_mul'")

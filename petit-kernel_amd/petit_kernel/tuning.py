@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 
-_KLASS = {"exact": 0, "native_mxfp8": 8, "native_mxfp4": 4}
+_KLASS = {"exact": 0, "native_mxfp8": 8, "native_mxfp6": 6, "native_mxfp4": 4}
 
 _reserved = {}   # device index -> the tensor the library's tuner draws from (kept alive here)
 

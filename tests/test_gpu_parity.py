@@ -1562,6 +1562,76 @@ def test_native_fp4_activations(pk, m, n, k, is_bf16):
         pk.ops.enable_native_fp4(False)
 
 
+E2M3_GRID = np.array([i / 8.0 for i in range(8)] + [(1.0 + i / 8.0) * 2.0 ** e for e in range(3) for i in range(8)])
+
+
+def quantize_act_mxfp6(a_f32: np.ndarray) -> np.ndarray:
+    """CPU statement of quantize_act32_fp6_kernel (csrc/gemm_native32.hpp): per 32-k block the OCP-MX scale 2^(E - 2), E the exponent of the
+    block maximum (so the maximum lands in [4, 8)), elements rounded to e2m3 -- round-to-nearest-even on the grid 0, 1/8 .. 7/8 (subnormals),
+    1 .. 1.875, 2 .. 3.75, 4 .. 7.5, saturating at 7.5 (v_cvt_scalef32_pk32_fp6_*, tools/probes/mfma32_fp6_probe.hip).  Returns the
+    DEQUANTISED activations."""
+    m, k = a_f32.shape
+    blk = a_f32.reshape(m, k // 32, 32).astype(np.float64)
+    amax = np.abs(blk).max(axis=2)
+    ebits = (amax.astype(np.float32).view(np.uint32) >> 23) & 0xFF
+    sbyte = np.where(amax == 0, 127, np.clip(ebits.astype(np.int64) - 2, 1, 254))
+    scale = np.ldexp(1.0, sbyte - 127)[:, :, None]
+    x = np.abs(blk) / scale
+    idx = np.searchsorted(E2M3_GRID, x, side="left").clip(1, 31)
+    lo, hi = E2M3_GRID[idx - 1], E2M3_GRID[idx]
+    pick_hi = (x - lo > hi - x) | ((x - lo == hi - x) & (idx % 2 == 0))      # ties: the even code (grid index = code)
+    q = np.where(x >= 7.5, 7.5, np.where(pick_hi, hi, lo))
+    return (np.sign(blk) * q * scale).reshape(m, k).astype(np.float32)
+
+
+@pytest.mark.parametrize("is_bf16", [True, False])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512), (5, 64, 1024), (1, 128, 768), (257, 160, 1280), (200, 512, 4096)])
+def test_native_mxfp6_activations(pk, m, n, k, is_bf16):
+    """FP4 x FP6 (MXFP4 weights raw, activations quantised on the fly to MXFP6 e2m3: the instruction still runs at its FP4 rate, the elements carry
+    e4m3's three mantissa bits).  Opt-in, ids carry mfma_type 4, sentinel -4.  (1) exact semantics: against the oracle run on the CPU-emulated
+    MXFP6 activations the kernel is within the usual 1e-2 bound.  (2) stated end-to-end tolerance against the unquantised oracle: the MXFP8
+    class's bounds -- e2m3 carries 2^-4 relative error per element in its three normal binades, 1/64 of the block maximum below them, and clips
+    a block maximum in (7.5, 8) scale units by at most 6 %."""
+    a_bits, q, s, gs = random_problem("mx", m, n, k, 6161 + m + n + k, is_bf16)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.b_type = pk.DataType.mxfloat4_e2m1
+    pk.ops.enable_native_fp4(True)
+    try:
+        fp6 = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 32) & 7 == 4]
+        assert fp6 and all((sid >> 48) & 0xF == 13 for sid in fp6)
+        a_f32 = to_f32(a_bits, is_bf16)
+        a_q = quantize_act_mxfp6(a_f32)
+        dq = O.dequant_mxfp4(q, s)
+        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq, gs)       # (5 significant bits x power of two: exact in bf16)
+        _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)
+        sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
+        for sid in fp6:
+            for splitk in (1, 2):
+                sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sk), is_bf16).astype(np.float64)
+                err = np.abs(c - exact)[fin]
+                assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all(), f"{sk:#x} max {err.max()}"
+                assert (np.abs(c - full)[fin] <= 2e-2 * sum_abs[fin] + 1e-2).all(), f"{sk:#x}"
+                assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 6e-2 * np.sqrt(np.mean(full[fin] ** 2)), f"{sk:#x}"
+        # the class sentinel on its own entry point: an enumerated kernel of the class, same numbers
+        qd = torch.from_numpy(q).to(DEV)
+        b = pk.repack_mxfp4(qd.view(torch.int32), n, k)
+        sp = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k)
+        gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+        ad = from_bits(a_bits, h.a_type).to(DEV)
+        c_auto = to_f32(bits(pk.mul_mxfp4_native(ad, b, sp, gsd, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP6)), is_bf16).astype(np.float64)
+        assert (np.abs(c_auto - exact)[fin] <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all()
+        # pre-quantised activations (one launch) are bit-identical to quantising inside the call
+        qa = pk.quantize_activations(ad, "mxfp6")
+        c_pre = pk.mul_mxfp4_native(qa, b, sp, gsd, m, n, k, fp6[0])
+        c_fly = pk.mul_mxfp4_native(ad, b, sp, gsd, m, n, k, fp6[0])
+        assert torch.equal(c_pre.view(torch.int16), c_fly.view(torch.int16))
+    finally:
+        pk.ops.enable_native_fp4(False)
+
+
 @pytest.mark.parametrize("is_bf16", [True, False])
 @pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512), (5, 64, 1024), (1, 128, 512), (257, 160, 1280)])
 def test_native_mxfp4(pk, m, n, k, is_bf16):
