@@ -23,7 +23,7 @@ The rest of the metric ("TFLOPS + achieved HBM GB/s, M in {1,8,16,512}, Llama-70
 test_bench_cells_parity so that every timed cell is also checked against the oracle): for qkv / o / gate_up / down,
 bf16 x NVFP4 at M in {1, 4, 8, 16, 512}, fp16 x NVFP4 (the reference benchmark's default dtype, tools/benchmarks/matmul.py:92-127)
 at M in {16, 512}, fp16 x MXFP4 (BASELINE configs[3]) at M in {1, 16}, bf16 x MXFP4 at M = 512 -- all through solution_id = -1 --
-plus at M = 512 the opt-in native-FP4 class through its own default pick (solution_id = -2 / -3) and an explicit hipBLASLt
+plus at M = 512 the opt-in native-FP4 class through its own default pick (solution_id = -2 / -4 / -3: MXFP8 / MXFP6 / MXFP4 activations) and an explicit hipBLASLt
 bf16 GEMM on a dense weight of the same shape (the reference's comparator, matmul/rocm/matmul_hipblaslt.cc:103-123), all
 measured in one child process with tools/benchlib.py.
 
@@ -120,8 +120,8 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
                 sink.flush()
     cells = Cells()
     mode_sid = {"auto": _lib.PETIT_SOLUTION_AUTO, "native_mxfp8": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8,
-                "native_mxfp4": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4}
-    peak = {"auto": BL.BF16_PEAK_TFLOPS, "native_mxfp8": BL.FP8_PEAK_TFLOPS, "native_mxfp4": BL.FP4_PEAK_TFLOPS, "hipblaslt": BL.BF16_PEAK_TFLOPS}
+                "native_mxfp6": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, "native_mxfp4": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4}
+    peak = {"auto": BL.BF16_PEAK_TFLOPS, "native_mxfp8": BL.FP8_PEAK_TFLOPS, "native_mxfp6": BL.FP4_PEAK_TFLOPS, "native_mxfp4": BL.FP4_PEAK_TFLOPS, "hipblaslt": BL.BF16_PEAK_TFLOPS}
     weights = {}                         # one rotating weight set alive at a time: (shape, w)
     for cell in BL.bench_cell_plan():
         shape, m, a, w, mode = cell["shape"], cell["M"], cell["a"], cell["w"], cell["mode"]
@@ -188,7 +188,7 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
         torch.cuda.empty_cache()
     return {"cells": cells, "cells_notes": notes, "cells_seconds": round(time.time() - t0, 1),
             "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, median of 5-7 replays; "
-                            "rate = GB/s (M <= 16) or TFLOP/s; frac = rate / 8000 GB/s, or / 2500 TFLOP/s (native_mxfp8 / 5000, native_mxfp4 / 10000, "
+                            "rate = GB/s (M <= 16) or TFLOP/s; frac = rate / 8000 GB/s, or / 2500 TFLOP/s (native_mxfp8 / 5000, native_mxfp6 and native_mxfp4 / 10000, "
                             "both launches timed); hipblaslt = vendor dense bf16 GEMM (HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm); "
                             "us_min, kernel id and description per cell: gpurun_out/bench_cells_full.json"}
 

@@ -206,8 +206,9 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
                                                         const unsigned m_total, const unsigned n_half, const unsigned m_first,
                                                         const unsigned col0, const unsigned kt, const unsigned wn, const unsigned m_l,
                                                         const unsigned h, unsigned char *lds_scales, const unsigned m0, const unsigned tid) {
-    constexpr unsigned kRowB = 16 * OUTF; // bytes per row and k-tile: 128 (FP8) / 64 (FP4)
+    constexpr unsigned kRowB = OUTF == 6 ? 64 : 16 * OUTF; // bytes per row and k-tile: 128 (FP8) / 64 (FP4; FP6: of the image of registers 0-3)
     unsigned char *const qs = out + (size_t)m_total * (n_half / 8 * OUTF);
+    unsigned char *const out_hi = out + (size_t)m_total * (n_half / 2); // FP6: the image of registers 4-5 (native32_ws_bytes)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         const unsigned m = m_first + mb * 32;
@@ -238,7 +239,46 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
         sbyte = sbyte > 254u ? 254u : sbyte;
         if (h == 0)
             lds_scales[(mb * 32 + m_l) * 4 + wn] = (unsigned char)sbyte;
-        if constexpr (OUTF == 4) {
+        if constexpr (OUTF == 6) {
+            // the block's 32 columns are this lane's 16 and its partner's (lane ^ 32) 16: each converts a 32-wide vector that holds its own values at
+            // their column positions and zeros (code 0) elsewhere; the two results OR into the block's 6 registers.  v_cvt_scalef32_2xpk16_fp6_f32
+            // interleaves its sources (element 2 t = a[t], 2 t + 1 = b[t]: tools/probes/mfma32_fp6_probe.hip); column np 16 + u 8 + 4 h + i.
+            typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
+            const float scale = __builtin_bit_cast(float, sbyte << 23);
+            f32x16 ea, eb;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                ea[t] = 0.f, eb[t] = 0.f;
+#pragma unroll
+            for (int np = 0; np < 2; ++np)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) { // (static indices: both halves written, the foreign one with zeros)
+                        const bool mine = h == (unsigned)hh;
+                        const int t = np * 8 + u * 4 + 2 * hh;
+                        ea[t] = mine ? v[np][u][0] : ea[t], eb[t] = mine ? v[np][u][1] : eb[t];
+                        ea[t + 1] = mine ? v[np][u][2] : ea[t + 1], eb[t + 1] = mine ? v[np][u][3] : eb[t + 1];
+                    }
+            const u32x6 own = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ea, eb, scale);
+            unsigned full[6];
+#pragma unroll
+            for (int d = 0; d < 6; ++d) {
+                const unsigned x = own[d];
+                const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+                const unsigned p0 = sw[0], p1 = sw[1];
+                full[d] = p0 | p1;
+            }
+            if (m < m_total) {
+                if (h == 0) {
+                    *reinterpret_cast<u32x4 *>(out + ((size_t)kt * m_total + m) * 64 + 16 * wn) = u32x4{full[0], full[1], full[2], full[3]};
+                } else {
+                    uint2 tail;
+                    tail.x = full[4], tail.y = full[5];
+                    *reinterpret_cast<uint2 *>(out_hi + ((size_t)kt * m_total + m) * 32 + 8 * ((wn & 1u) * 2 + (wn >> 1))) = tail;
+                }
+            }
+        } else if constexpr (OUTF == 4) {
             const float scale = __builtin_bit_cast(float, sbyte << 23);
             unsigned q[2];
 #pragma unroll
@@ -893,6 +933,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 const unsigned col0 = (nt0 >> 1) * 16;
                 if (p.out_format == 4)
                     n32_silu_quant_epilogue<AT, 4, MB>(acc, gs, p.bias, (unsigned char *)p.c, p.m, n_half, m_base, col0, bn, wn, m_l, h, lds_sc, m0, tid);
+                else if (p.out_format == 6)
+                    n32_silu_quant_epilogue<AT, 6, MB>(acc, gs, p.bias, (unsigned char *)p.c, p.m, n_half, m_base, col0, bn, wn, m_l, h, lds_sc, m0, tid);
                 else
                     n32_silu_quant_epilogue<AT, 8, MB>(acc, gs, p.bias, (unsigned char *)p.c, p.m, n_half, m_base, col0, bn, wn, m_l, h, lds_sc, m0, tid);
                 return;

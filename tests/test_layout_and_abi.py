@@ -614,7 +614,7 @@ def test_native_class_default_picks():
         at, bt, n, k, lo, sol = int(at), int(bt), int(n), int(k), int(lo), int(sol, 16)
         assert bt == _lib.CXX_DTYPE_MXFP4_E2M1 and (sol >> 48) & 0xF in (9, 13)
         h = _lib.SolutionHints(at, bt, at, 0)
-        sentinel = _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4 if (sol >> 32) & 7 == 6 else _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8
+        sentinel = {6: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 4: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, 2: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8}[(sol >> 32) & 7]
         assert L.petit_gemm_resolve_solution(C.byref(h), lo, n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == sol
         assert "unknown" not in _lib.describe_solution(sol)
     for at in (_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP16):
@@ -622,7 +622,7 @@ def test_native_class_default_picks():
         for (m, n, k) in [(512, 5120, 13824), (64, 96, 512), (2048, 57344, 8192), (300, 4096, 768), (17, 32, 256)]:   # unseen shapes, every span size
             exact = L.petit_gemm_default_solution(C.byref(h), m, n, k)
             assert exact and (exact >> 48) & 0xF not in (9, 13)
-            for sentinel, code in ((_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, 2), (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 6)):
+            for sentinel, code in ((_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, 2), (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, 4), (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 6)):
                 sid = L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40))
                 assert sid and (sid >> 48) & 0xF in (9, 13) and (sid >> 32) & 7 == code, (m, n, k, hex(sid))
                 need = L.petit_gemm_workspace_bytes(C.byref(h), m, n, k, C.c_uint64(sentinel))
@@ -679,7 +679,8 @@ def test_new_entry_points_validate_before_they_launch():
     # sizes of the quantised-activation format
     assert L.petit_quantized_activation_bytes(512, 8192, 4) == 512 * 8192 // 2 + 512 * 8192 // 32
     assert L.petit_quantized_activation_bytes(512, 8192, 8) == 512 * 8192 + 512 * 8192 // 32 == L.petit_native_workspace_bytes(512, 8192)
-    assert L.petit_quantized_activation_bytes(512, 8192, 6) == 0
+    assert L.petit_quantized_activation_bytes(512, 8192, 6) == 512 * 8192 * 3 // 4 + 512 * 8192 // 32      # MXFP6: 24 bytes per 32-k block
+    assert L.petit_quantized_activation_bytes(512, 8192, 5) == 0
     assert L.petit_quantize_activations(fake, fake, 4, 1000, _lib.CXX_DTYPE_BF16, 4, None) == _lib.PETIT_ERROR_PROBLEM_SHAPE
     assert L.petit_quantize_activations(fake, fake, 4, 1024, 3, 4, None) == _lib.PETIT_ERROR_KERNEL_SHAPE                   # not a 16-bit activation type
     assert L.petit_quantize_activations(None, fake, 4, 1024, _lib.CXX_DTYPE_BF16, 4, None) == _lib.PETIT_ERROR_BAD_ARGUMENT

@@ -27,7 +27,7 @@ for s in shapes:
     print(f"| {s} | " + " | ".join(f"{cells[(s, m, dt)]['us']:.2f} us, {cells[(s, m, dt)]['frac']:.2f} / {cells[(s, m, dt)]['GBs'] / COPY_CEILING:.2f}" if (s, m, dt) in cells else "-"
                                    for dt, m in cols) + " |")
 print("\nM = 512 (TFLOP/s; fraction of 2.5 PF bf16 peak, native: of the 5 / 10 PF FP8 / FP4 peaks; native cells include the activation-quantiser launch):\n")
-cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("fp16xmx", "fp16 x MXFP4"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"),
+cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("fp16xmx", "fp16 x MXFP4"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"), ("bf16xmx native_mxfp6", "native, act -> MXFP6 (-4)"),
         ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xdense hipblaslt", "hipBLASLt bf16 dense")]
 print("| shape | " + " | ".join(name for _, name in cols) + " |")
 print("|---|" + "---|" * len(cols))

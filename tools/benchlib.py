@@ -36,7 +36,7 @@ LLAMA70B = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "
 # shapes" + configs[2] M = 4, configs[3] fp16 x MXFP4, configs[4] native FP4 / hipBLASLt, and the reference benchmark's own default
 # dtype, fp16 x NVFP4, tools/benchmarks/matmul.py:92-127), in the order bench.py measures it.  tests/test_gpu_parity.py::
 # test_bench_cells_parity iterates the SAME list, so every (shape, M, dtype, mode) that is timed is also checked against the oracle.
-#   mode: "auto" = solution_id -1; "native_mxfp8" / "native_mxfp4" = the opt-in native class through its own default pick;
+#   mode: "auto" = solution_id -1; "native_mxfp8" / "native_mxfp6" / "native_mxfp4" = the opt-in native class through its own default pick;
 #   "hipblaslt" = the vendor's dense 16-bit GEMM on a dense weight of the same shape (comparator, no parity to check)
 SHAPE_ORDER = ("qkv", "o", "gate_up", "down")
 
@@ -54,7 +54,8 @@ def bench_cell_plan() -> list:
         plan += [dict(shape=shape, M=256, a="fp16", w="nv", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="nv", mode="auto"), dict(shape=shape, M=512, a="fp16", w="nv", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"), dict(shape=shape, M=512, a="fp16", w="mx", mode="auto"),
-                 dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
+                 dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp6"),
+                 dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
                  dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt")]
     # launch-gap-bound shapes: the q / k / v shards of a TP-8 deployment (1280 x 8192 each) as three launches and as one grouped launch
     plan += [dict(shape="tp8_qkv_3x1280", M=m, a="bf16", w="nv", mode=mode) for m in (1, 16) for mode in ("separate", "grouped")]
@@ -224,9 +225,10 @@ class MlpBlock:
       exact                     default kernels (bf16 activations), fused SiLU-mul: 2 launches
       native_mxfp4_4launch      the native class call by call: quantiser + GEMM, twice: 4 launches
       native_mxfp4_pipeline     quantise x once, gate_up emits the quantised h (out_quantized), down reads it: 3 launches
+      native_mxfp8_pipeline / native_mxfp6_pipeline   the same with MXFP8 / MXFP6 (e2m3) activations: the deployable accuracy class
     (petit_kernel.mul_mxfp4_native; weights of both GEMMs rotate over copies so that nothing is served by the Infinity Cache)."""
 
-    MODES = ("exact", "native_mxfp4_4launch", "native_mxfp4_pipeline", "native_mxfp8_pipeline")
+    MODES = ("exact", "native_mxfp4_4launch", "native_mxfp4_pipeline", "native_mxfp8_pipeline", "native_mxfp6_pipeline")
 
     def __init__(self, m: int, dev, hidden: int = 8192, inter: int = 28672, rotate_mb: int = 1280):
         self.m, self.hidden, self.inter = m, hidden, inter
@@ -244,8 +246,8 @@ class MlpBlock:
         if mode == "exact":
             h = pk.mul_mxfp4_a16(self.x, b1, s1, gs, m, 2 * inter, hid, -1, activation="silu_mul")
             return pk.mul_mxfp4_a16(h, b2, s2, gs, m, hid, inter, -1)
-        fmt = "mxfp8" if "mxfp8" in mode else "mxfp4"
-        sid = pk.SOLUTION_AUTO_NATIVE_MXFP8 if fmt == "mxfp8" else pk.SOLUTION_AUTO_NATIVE_MXFP4
+        fmt = "mxfp8" if "mxfp8" in mode else "mxfp6" if "mxfp6" in mode else "mxfp4"
+        sid = {"mxfp8": pk.SOLUTION_AUTO_NATIVE_MXFP8, "mxfp6": pk.SOLUTION_AUTO_NATIVE_MXFP6, "mxfp4": pk.SOLUTION_AUTO_NATIVE_MXFP4}[fmt]
         if mode.endswith("4launch"):
             h = pk.mul_mxfp4_native(self.x, b1, s1, gs, m, 2 * inter, hid, sid, activation="silu_mul")
             return pk.mul_mxfp4_native(h, b2, s2, gs, m, hid, inter, sid)
