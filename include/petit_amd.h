@@ -285,7 +285,9 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
 /*
  * Native-FP4 kernels (no counterpart in the reference): MXFP4 weights go straight into the CDNA4
  * block-scaled MFMA and the 16-bit activations are quantised on the fly to MXFP8 (e4m3 + one e8m0
- * scale per 32 k).  That quantisation costs ~2^-4 relative per activation, so these kernels are a
+ * scale per 32 k), MXFP6 (e2m3: the same three mantissa bits over three binades, at the instruction's
+ * FP4 rate; mfma_type 4) or MXFP4 (e2m1; mfma_type 6: experimental accuracy).  That quantisation costs
+ * ~2^-4 (e4m3, e2m3) / 2^-2 (e2m1) relative per activation, so these kernels are a
  * different accuracy class: they are NEVER chosen by PETIT_SOLUTION_AUTO and are only enumerated
  * by petit_gemm_get_solutions after petit_enable_native_fp4(1) (or $PETIT_AMD_NATIVE_FP4=1).  Their
  * ids carry mfma_type = 2 (the reference's unused kMatmulMfmaTypeFp8, gemm.h:20-24).  They need a
@@ -297,11 +299,11 @@ uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);
 /*
  * The native class as a PIPELINE (no counterpart in the reference).  petit_gemm_mxfp4_fp16_grid_ws with a native id runs two
  * launches per GEMM (activation quantiser, then the block-scaled-MFMA kernel).  Two hand-over points remove the quantiser:
- *   a_format   8 / 4: `a` is not the 16-bit matrix but activations ALREADY quantised to MXFP8 / MXFP4 for (m, k), produced by
+ *   a_format   8 / 6 / 4: `a` is not the 16-bit matrix but activations ALREADY quantised to MXFP8 / MXFP6 / MXFP4 for (m, k), produced by
  *              petit_quantize_activations() (once, for any number of GEMMs that share the input: q / k / v, gate / up) or by
  *              a producer GEMM's epilogue (next item).  The bytes are opaque ("petit-qact/1": k-tile-major, the 32x32x64
  *              kernels' operand order); petit_quantized_activation_bytes() sizes them.  0: `a` is the 16-bit [m][k] matrix.
- *   out_format 8 / 4, with epilogue->activation = PETIT_ACTIVATION_SILU_MUL: `c` receives silu(y_gate) * y_up QUANTISED for the
+ *   out_format 8 / 6 / 4, with epilogue->activation = PETIT_ACTIVATION_SILU_MUL: `c` receives silu(y_gate) * y_up QUANTISED for the
  *              next GEMM (m, k' = n / 2) -- petit_quantized_activation_bytes(m, n / 2, out_format) bytes -- instead of the
  *              16-bit [m][n/2] matrix: gate_up -> SiLU-mul -> down of a gated MLP in two launches.  Needs n % 512 == 0 and a
  *              kernel with 128 x 256 workgroup tiles (the sentinels pick one).  Quantised from the f32 result with the
