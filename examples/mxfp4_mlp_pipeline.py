@@ -2,7 +2,7 @@
 """examples/mxfp4_mlp_pipeline.py -- the round-3 extensions on one gated-MLP block with MXFP4 weights (needs an MI355X):
 
   1. exact:     bf16 activations end to end, SiLU-mul fused into gate_up's epilogue            (solution_id = -1)
-  2. pipeline:  the opt-in native FP4 class -- quantise x once, gate_up emits the quantised h, down reads it (solution_id = -3)
+  2. pipeline:  the opt-in native FP4 class -- quantise x once, gate_up emits the quantised h, down reads it (solution_id = -4 / -2 / -3: MXFP6 / MXFP8 / MXFP4 activations)
   3. grouped:   gate and up kept as two tensors, one launch for both (decode batch)              (mul_fp4_a16_grouped)
   4. tuning:    petit_kernel.tune_tensors on the layer's own tensors; solution_id = -1 uses the winner from then on
 
@@ -36,11 +36,13 @@ def main() -> None:
     h = pk.mul_mxfp4_a16(x, b1, s1, gs, m, 2 * inter, hidden, -1, activation="silu_mul")
     y_exact = pk.mul_mxfp4_a16(h, b2, s2, gs, m, hidden, inter, -1)
 
-    xq = pk.quantize_activations(x, "mxfp4")
-    hq = pk.mul_mxfp4_native(xq, b1, s1, gs, m, 2 * inter, hidden, pk.SOLUTION_AUTO_NATIVE_MXFP4, activation="silu_mul", out_quantized="mxfp4")
-    y_fp4 = pk.mul_mxfp4_native(hq, b2, s2, gs, m, hidden, inter, pk.SOLUTION_AUTO_NATIVE_MXFP4)
-    rel = ((y_fp4.float() - y_exact.float()).pow(2).mean().sqrt() / y_exact.float().pow(2).mean().sqrt()).item()
-    print(f"native FP4 x FP4 pipeline vs exact kernels: rms difference {100 * rel:.1f} % of the output rms (an accuracy class of its own: DESIGN.md 3.3)")
+    # the native class, three activation formats: MXFP6 (e2m3: e4m3's mantissa at the instruction's FP4 rate) is the one to serve with
+    for fmt, sentinel in (("mxfp6", pk.SOLUTION_AUTO_NATIVE_MXFP6), ("mxfp8", pk.SOLUTION_AUTO_NATIVE_MXFP8), ("mxfp4", pk.SOLUTION_AUTO_NATIVE_MXFP4)):
+        xq = pk.quantize_activations(x, fmt)
+        hq = pk.mul_mxfp4_native(xq, b1, s1, gs, m, 2 * inter, hidden, sentinel, activation="silu_mul", out_quantized=fmt)
+        y_q = pk.mul_mxfp4_native(hq, b2, s2, gs, m, hidden, inter, sentinel)
+        rel = ((y_q.float() - y_exact.float()).pow(2).mean().sqrt() / y_exact.float().pow(2).mean().sqrt()).item()
+        print(f"native pipeline, activations -> {fmt}: rms difference to the exact kernels {100 * rel:.1f} % of the output rms (an accuracy class of its own: DESIGN.md 3.3)")
 
     # decode batch, gate and up as two tensors: two launches vs one
     bg, sg = mx_weights(inter, hidden, g, dev)
