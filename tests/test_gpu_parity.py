@@ -1728,6 +1728,10 @@ def test_in_library_tune_picks_checks_and_persists(pk, tmp_path):
             assert (nsid >> 48) & 0xF == 13 and (nsid >> 32) & 7 == 6 and nus > 0
             assert pk.ops.resolve_solution(h, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP4) == nsid
             assert pk.ops.resolve_solution(h, m, n, k, -1) == sid          # the exact class is untouched by it
+            n6, us6 = pk.tune_tensors(a, (b, sp), gsd, m, n, k, kind="mxfp4", klass="native_mxfp6", rotate_mb=96)
+            assert (n6 >> 48) & 0xF == 13 and (n6 >> 32) & 7 == 4 and us6 > 0
+            assert pk.ops.resolve_solution(h, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP6) == n6
+            assert pk.ops.resolve_solution(h, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP4) == nsid   # each class keeps its own row
     path = tmp_path / "tuned.txt"
     pk.tuning.save(path)
     rows = [ln.split() for ln in path.read_text().splitlines() if ln and not ln.startswith("#")]
