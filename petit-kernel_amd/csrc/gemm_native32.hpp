@@ -1,11 +1,14 @@
-// gemm_native32.hpp -- the native-FP4 path on the 32x32x64 block-scaled MFMA, with FP8 or FP4 activations.
+// gemm_native32.hpp -- the native-FP4 path on the 32x32x64 block-scaled MFMA, with FP8, FP6 or FP4 activations.
 //
 // MXFP4 weights go RAW into v_mfma_scale_f32_32x32x64_f8f6f4 (zero unpack VALU); the 16-bit activations are quantised on
-// the fly by a first small kernel, either to MXFP8 (e4m3 elements + one e8m0 scale per 32 k: the instruction then runs at
-// the FP8 rate, 5 PFLOP/s dense) or to MXFP4 (e2m1 elements + e8m0 per 32 k: FP4 x FP4, the 10 PFLOP/s rate MI355X
-// quotes for its hardware FP4).  OPT-IN, like gemm_native.hpp: quantising activations is a different accuracy class
-// (e4m3: 2^-4 relative per element, e2m1: 2^-2), never chosen by solution_id = -1; ids carry mfma_type 2 (FP8
-// activations) or 6 (FP4 activations).  Exact-semantics + stated-tolerance tests: tests/test_gpu_parity.py.
+// the fly by a first small kernel to one of three block-scaled formats (one e8m0 scale per 32 k each):
+//   MXFP8 (e4m3 elements): the instruction then runs at the FP8 rate, 5 PFLOP/s dense;
+//   MXFP6 (e2m3 elements): the instruction runs at its FP4 rate as long as neither operand is 8-bit -- e4m3's three mantissa
+//          bits over three binades (subnormals of 1/8 below) at the 10 PFLOP/s rate;
+//   MXFP4 (e2m1 elements): FP4 x FP4, the rate MI355X quotes for its hardware FP4.
+// OPT-IN, like gemm_native.hpp: quantising activations is a different accuracy class (e4m3 / e2m3: 2^-4 relative per element,
+// e2m1: 2^-2), never chosen by solution_id = -1; ids carry mfma_type 2 (FP8 activations), 4 (FP6) or 6 (FP4).
+// Exact-semantics + stated-tolerance tests: tests/test_gpu_parity.py.
 //
 // What differs from gemm_native.hpp (16x16x128, FP8 only):
 //  * 32x32x64 instruction: two neighbouring n-tiles are merged in registers with two lane swaps per packed word
@@ -18,6 +21,7 @@
 // Operand layouts probed on gfx950 (tools/probes/mfma32_layout_probe.hip):
 //   FP4 operand (A and B)  lane (row|col = l%32, h = l/32): regs 0-3, k = 32h + 8*reg + nibble   (natural)
 //   FP8 operand (B)        lane (col, h): regs 0-3 k = 16h .. 16h+15, regs 4-7 k = 32 + 16h .. 32+16h+15
+//   FP6 operand (B)        lane (col, h): 32 elements of 6 bits in regs 0-5, k = 32h + element   (tools/probes/mfma32_fp6_probe.hip)
 //   scales                 the E8M0 byte of block b (k in [32b, 32b+32)) comes from lanes l/32 = b of the same row/column
 #pragma once
 
@@ -324,7 +328,7 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
         *reinterpret_cast<unsigned *>(qs + ((size_t)kt * m_total + m0 + tid) * 4) = reinterpret_cast<const unsigned *>(lds_scales)[tid];
 }
 
-//   MB, NP, WAVES, D as in WideCfg; ACT = 8 (MXFP8 activations) or 4 (MXFP4 activations).
+//   MB, NP, WAVES, D as in WideCfg; ACT = 8 (MXFP8 activations), 6 (MXFP6, e2m3) or 4 (MXFP4 activations).
 //   KT   k-tiles per barrier ("stage"): the quantised activation tile is small (128 / 64 bytes per row and k-tile), and with
 //        zero unpack work a k-tile is only 2*MB*NP MFMAs, so one barrier per tile leaves the wave waiting on it.
 //   PF   stages requested ahead (NBUF = PF + 1 LDS stages): 1 = the next stage is requested at the top of a stage and waited
