@@ -295,6 +295,14 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
  */
 int petit_enable_native_fp4(int enable);
 uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);
+/* A process-wide opt-in for call sites that cannot name a sentinel (an unchanged serving stack calls the MXFP4 entry points with
+ * PETIT_SOLUTION_AUTO): activation_format 8 / 6 / 4 makes PETIT_SOLUTION_AUTO on MXFP4 weights run the default pick of THAT native
+ * class (MXFP8 / MXFP6 / MXFP4 activations) for m >= $PETIT_AMD_NATIVE_MIN_M (default 64), whenever the call has the scratch the class
+ * needs (petit_gemm_workspace_bytes(.., PETIT_SOLUTION_AUTO) then reports it; both Python layers pass it per call) -- without scratch the
+ * exact default runs, as before.  0 switches it off (the default).  Initial value: $PETIT_AMD_MXFP4_ACTIVATIONS = mxfp8 | mxfp6 | mxfp4.
+ * NVFP4 weights, explicit ids and the sentinels are not affected. */
+int petit_set_mxfp4_default_class(int activation_format);
+int petit_get_mxfp4_default_class(void);
 
 /*
  * The native class as a PIPELINE (no counterpart in the reference).  petit_gemm_mxfp4_fp16_grid_ws with a native id runs two

@@ -515,6 +515,36 @@ int auto_class(uint64_t solution_id) {
 }
 bool is_auto_id(uint64_t solution_id) { return solution_id == PETIT_SOLUTION_AUTO || auto_class(solution_id) != kClassExact; }
 
+// A process-wide opt-in for call sites that cannot name a sentinel (an unchanged SGLang / vLLM layer calls mul_mxfp4_a16(..., -1)):
+// $PETIT_AMD_MXFP4_ACTIVATIONS = mxfp8 | mxfp6 | mxfp4, or petit_set_mxfp4_default_class(), makes PETIT_SOLUTION_AUTO on MXFP4 weights
+// mean "the default pick of THAT native class" for m >= $PETIT_AMD_NATIVE_MIN_M (default 64: below it the exact kernels are HBM-bound and
+// the 128-row native tiles buy nothing) -- whenever the call has the scratch the class needs; without it the exact default runs, as
+// before.  Off by default: quantised activations are another accuracy class.
+std::atomic<int> g_mxfp4_default_class{-1}; // -1: not read yet
+unsigned native_min_m() {
+    static const unsigned v = [] {
+        const char *e = getenv("PETIT_AMD_NATIVE_MIN_M");
+        const long x = e ? strtol(e, nullptr, 10) : 64;
+        return (unsigned)(x < 1 ? 1 : x);
+    }();
+    return v;
+}
+int mxfp4_default_class() {
+    int v = g_mxfp4_default_class.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("PETIT_AMD_MXFP4_ACTIVATIONS");
+        v = !e ? 0 : !strcmp(e, "mxfp8") ? kClassNativeFp8 : !strcmp(e, "mxfp6") ? kClassNativeFp6 : !strcmp(e, "mxfp4") ? kClassNativeFp4 : 0;
+        g_mxfp4_default_class.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// the class PETIT_SOLUTION_AUTO stands for on this problem (kClassExact unless the process opted in, see above)
+int auto_default_class(uint64_t solution_id, int b_type, unsigned m) {
+    if (solution_id != PETIT_SOLUTION_AUTO || b_type != kDataTypeMxFp4e2m1 || m < native_min_m())
+        return kClassExact;
+    return mxfp4_default_class();
+}
+
 // An explicit id -> table entry.  The element_b nibble is forced to the entry point's format first, as the reference
 // does (gemm_fp4_fp16_grid.cc:79-95): ids enumerated with b_type = FP4_E2M1 (what get_fp4_solutions(m, n, k, a, c)
 // returns) therefore work with mul_mxfp4_a16; the block-floating-point staged kernels, which only exist for
@@ -631,7 +661,17 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
 
     const int dev = current_device();
     const bool is_auto = is_auto_id(solution_id);
-    const int klass = auto_class(solution_id);
+    int klass = auto_class(solution_id);
+    if (const int dflt = (restrict_ == 0) ? auto_default_class(solution_id, b_type, m) : kClassExact) {
+        // the process-wide default class: taken when the scratch of this call (its own, else the registered one) covers the class's pick
+        const AutoChoice chn = choose_auto(fam, dev, hints->a_type, b_type, act, m, n, k, dflt, 0);
+        if (chn.entry) {
+            const uint64_t need_n = workspace_need(*chn.entry, chn.splitk, m, n, k);
+            bool busy = false;
+            if (call_ws ? call_ws_bytes >= need_n : registered_workspace(dev, stream, need_n, &busy) != nullptr)
+                klass = dflt;
+        }
+    }
     if (klass != kClassExact && b_type != kDataTypeMxFp4e2m1)
         return kErrKernelShape; // the native class exists for MXFP4 weights only (e4m3 group scales are not E8M0 block scales)
     if (restrict_ && is_auto && klass == kClassExact)
@@ -807,9 +847,11 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
     if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
         return 0;
     if (is_auto_id(solution_id)) {
-        const int klass = auto_class(solution_id);
+        int klass = auto_class(solution_id);
         if (klass != kClassExact && hints->b_type != kDataTypeMxFp4e2m1)
             return 0;
+        if (const int dflt = auto_default_class(solution_id, hints->b_type, m)) // (the process-wide default class: size the scratch it needs)
+            klass = dflt;
         const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, klass);
         return ch.entry ? workspace_need(*ch.entry, ch.splitk, m, n, k) : 0;
     }
@@ -969,9 +1011,14 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
             return 0;
         return make_solution_id(e->shape, fam.elem_b, entry_mfma(fam, *e), sk);
     }
-    const int klass = auto_class(solution_id);
+    int klass = auto_class(solution_id);
     if (klass != kClassExact && hints->b_type != kDataTypeMxFp4e2m1)
         return 0;
+    if (const int dflt = auto_default_class(solution_id, hints->b_type, m)) { // the process-wide default class, when `workspace_bytes` covers its pick (gemm_impl)
+        const AutoChoice chn = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, dflt);
+        if (chn.entry && workspace_need(*chn.entry, chn.splitk, m, n, k) <= workspace_bytes)
+            klass = dflt;
+    }
     AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, klass);
     if (ch.entry && workspace_need(*ch.entry, ch.splitk, m, n, k) > workspace_bytes) {
         // exactly what gemm_impl does when the caller's scratch does not cover the pick
@@ -1067,6 +1114,14 @@ int petit_enable_native_fp4(int enable) {
     g_native_enabled.store(enable ? 1 : 0);
     return kOk;
 }
+
+int petit_set_mxfp4_default_class(int activation_format) {
+    if (activation_format != 0 && activation_format != 8 && activation_format != 6 && activation_format != 4)
+        return kErrBadArgument;
+    g_mxfp4_default_class.store(activation_format, std::memory_order_relaxed);
+    return kOk;
+}
+int petit_get_mxfp4_default_class(void) { return mxfp4_default_class(); }
 
 uint64_t petit_native_workspace_bytes(unsigned m, unsigned k) { return native_ws_bytes(m, k); }
 

@@ -95,6 +95,8 @@ _SIGNATURES = {
     "petit_set_workspace": (C.c_int, [C.c_void_p, C.c_uint64]),
     "petit_workspace_bytes": (C.c_uint64, [C.c_uint64, C.c_uint, C.c_uint]),
     "petit_enable_native_fp4": (C.c_int, [C.c_int]),
+    "petit_set_mxfp4_default_class": (C.c_int, [C.c_int]),
+    "petit_get_mxfp4_default_class": (C.c_int, []),
     "petit_native_workspace_bytes": (C.c_uint64, [C.c_uint, C.c_uint]),
     "petit_gemm_fp4_fp16_grouped": (C.c_int, [C.POINTER(GroupMember), C.c_uint, C.c_void_p, C.c_uint, C.c_uint, C.POINTER(SolutionHints), C.c_uint64,
                                               C.c_void_p]),

@@ -289,6 +289,20 @@ def enable_native_fp4(enable: bool = True) -> None:
     _lib.lib.petit_enable_native_fp4(int(bool(enable)))
 
 
+def set_mxfp4_default_activations(fmt=None) -> None:
+    """Process-wide opt-in for call sites that cannot name a sentinel: fmt 'mxfp8' / 'mxfp6' / 'mxfp4' makes solution_id = -1 on MXFP4
+    weights (mul_mxfp4_a16 of an unchanged serving stack) run the default pick of that native class for size_m >= $PETIT_AMD_NATIVE_MIN_M
+    (64); None switches it off.  The same as $PETIT_AMD_MXFP4_ACTIVATIONS; quantised activations are another accuracy class."""
+    _check(fmt is None or fmt in _QFORMATS, "fmt must be None, 'mxfp8', 'mxfp6' or 'mxfp4'")
+    _raise_on(_lib.lib.petit_set_mxfp4_default_class(_QFORMATS[fmt] if fmt else 0), "set_mxfp4_default_activations")
+    _ws_need_cache.clear()      # (what AUTO needs as scratch has just changed)
+
+
+def mxfp4_default_activations():
+    v = int(_lib.lib.petit_get_mxfp4_default_class())
+    return {8: "mxfp8", 6: "mxfp6", 4: "mxfp4"}.get(v)
+
+
 def native_workspace_bytes(size_m: int, size_k: int) -> int:
     return int(_lib.lib.petit_native_workspace_bytes(size_m, size_k))
 

@@ -1697,6 +1697,46 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
         pk.ops.enable_native_fp4(False)
 
 
+def test_process_wide_default_class_runs_the_native_pick_behind_solution_id_minus_one(pk):
+    """set_mxfp4_default_activations('mxfp6') (= $PETIT_AMD_MXFP4_ACTIVATIONS): an UNCHANGED call site -- mul_mxfp4_a16(..., -1), either binding --
+    gets the MXFP6 class's default pick bit for bit at M >= 64, the exact kernel below that, on NVFP4 weights and through a C call without
+    scratch; switching it off restores the exact default."""
+    import ctypes as C
+    from petit_kernel import _lib
+    m, n, k = 192, 512, 2048
+    a_bits, q, s, gs, a, b, sp, gsd = _mx_problem_on_device(pk, m, n, k, 8800)
+    base = pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, -1)
+    base16 = pk.mul_mxfp4_a16(a[:16].contiguous(), b, sp, gsd, 16, n, k, -1)
+    assert pk.ops.mxfp4_default_activations() is None
+    ch = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+
+    def c_call_without_scratch():
+        c = torch.empty_like(base)
+        pk.ops.set_workspace(None)
+        rc = _lib.lib.petit_gemm_mxfp4_fp16_grid(c.data_ptr(), a.data_ptr(), b.data_ptr(), sp.data_ptr(), gsd.data_ptr(), m, n, k, C.byref(ch),
+                                                 C.c_uint64(_lib.PETIT_SOLUTION_AUTO), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert rc == 0
+        return c
+    base_c = c_call_without_scratch()
+    pk.ops.set_mxfp4_default_activations("mxfp6")
+    try:
+        want = pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP6)
+        assert not torch.equal(want.view(torch.int16), base.view(torch.int16))                      # (another accuracy class: it does differ)
+        for use_compiled in (True, False):
+            got = (pk.mul_mxfp4_a16 if use_compiled else pk.ops.mul_mxfp4_a16)(a, b, sp, gsd, m, n, k, -1)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+        assert torch.equal(pk.mul_mxfp4_a16(a[:16].contiguous(), b, sp, gsd, 16, n, k, -1).view(torch.int16), base16.view(torch.int16))
+        # the C entry point without any scratch: the exact default it ran before (a kernel that needs none), not an error
+        assert torch.equal(c_call_without_scratch().view(torch.int16), base_c.view(torch.int16))
+        # NVFP4 weights are not affected
+        an, qn, sn, gn = random_problem("nv", m, n, k, 8801, True)
+        check_gemm(run_case(pk, "nv", an, True, qn, sn, gn, m, n, k), oracle_ref("nv", an, True, qn, sn, gn), True, None)
+    finally:
+        pk.ops.set_mxfp4_default_activations(None)
+    assert torch.equal(pk.mul_mxfp4_a16(a, b, sp, gsd, m, n, k, -1).view(torch.int16), base.view(torch.int16))
+
+
 # --- tune-and-persist inside the library (csrc/tune.hip; the reference's `bench_matmul -algo tune`, main.cc:269-325) ------
 
 def test_in_library_tune_picks_checks_and_persists(pk, tmp_path):

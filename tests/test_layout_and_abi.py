@@ -636,6 +636,35 @@ def test_native_class_default_picks():
         assert L.petit_gemm_workspace_bytes(C.byref(hn), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)) == 0
 
 
+def test_process_wide_default_class_for_mxfp4_weights():
+    """petit_set_mxfp4_default_class (= $PETIT_AMD_MXFP4_ACTIVATIONS): PETIT_SOLUTION_AUTO on MXFP4 weights resolves inside the named native class
+    for m >= 64 when the scratch covers it, nowhere else; off by default; needs no GPU to decide."""
+    from petit_kernel import _lib
+    L = _lib.lib
+    mx = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    nv = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    auto = C.c_uint64(_lib.PETIT_SOLUTION_AUTO)
+    kind = lambda sid: (sid >> 48) & 0xF
+    assert L.petit_get_mxfp4_default_class() == 0
+    exact = {m: L.petit_gemm_default_solution(C.byref(mx), m, 8192, 8192) for m in (16, 512)}
+    assert all(kind(s) not in (9, 13) for s in exact.values())
+    assert L.petit_set_mxfp4_default_class(5) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    try:
+        for fmt, code in ((8, 2), (6, 4), (4, 6)):
+            assert L.petit_set_mxfp4_default_class(fmt) == 0 and L.petit_get_mxfp4_default_class() == fmt
+            sid = L.petit_gemm_default_solution(C.byref(mx), 512, 8192, 8192)
+            assert kind(sid) in (9, 13) and (sid >> 32) & 7 == code, hex(sid)
+            assert L.petit_gemm_workspace_bytes(C.byref(mx), 512, 8192, 8192, auto) >= 512 * 8192 // 2
+            # no scratch -> the exact default, as before; small M and NVFP4 weights: never
+            assert L.petit_gemm_resolve_solution(C.byref(mx), 512, 8192, 8192, auto, None, C.c_uint64(0)) == exact[512] or \
+                kind(L.petit_gemm_resolve_solution(C.byref(mx), 512, 8192, 8192, auto, None, C.c_uint64(0))) not in (9, 13)
+            assert L.petit_gemm_default_solution(C.byref(mx), 16, 8192, 8192) == exact[16]
+            assert kind(L.petit_gemm_default_solution(C.byref(nv), 512, 8192, 8192)) not in (9, 13)
+    finally:
+        assert L.petit_set_mxfp4_default_class(0) == 0
+    assert L.petit_gemm_default_solution(C.byref(mx), 512, 8192, 8192) == exact[512]
+
+
 def test_tune_params_struct_matches_the_header():
     from petit_kernel import _lib
     text = (ROOT / "include/petit_amd.h").read_text()
