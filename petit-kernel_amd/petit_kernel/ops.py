@@ -154,7 +154,7 @@ SOLUTION_AUTO_NATIVE_MXFP6 = -4
 
 def _c_solution_id(solution_id: int, native_ok: bool = False) -> int:
     """Python id -> the C ABI's uint64.  Any negative id is the library default, as in the reference (fp4.cc:189,240); the native-class
-    sentinels (-2 / -3) mean themselves only where the caller has opted into that class (mul_mxfp4_native, the resolve / workspace queries)."""
+    sentinels (-2 / -3 / -4) mean themselves only where the caller has opted into that class (mul_mxfp4_native, the resolve / workspace queries)."""
     solution_id = int(solution_id)
     if native_ok and solution_id == SOLUTION_AUTO_NATIVE_MXFP8:
         return _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8
@@ -316,7 +316,7 @@ def workspace_bytes(hints: PetitSolutionHints, size_m: int, size_n: int, size_k:
 
 def resolve_solution(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, solution_id: int = -1, activation=None,
                      workspace_bytes: int = 1 << 62) -> int:
-    """The concrete kernel id a call with these arguments runs (petit_gemm_resolve_solution): solution_id may be -1, -2 / -3
+    """The concrete kernel id a call with these arguments runs (petit_gemm_resolve_solution): solution_id may be -1, -2 / -3 / -4
     (default pick inside the native class) or an explicit id; 0 when the call would be refused."""
     ch = _c_hints(hints)
     act = _ACTIVATIONS[activation]
@@ -400,9 +400,9 @@ def quantize_activations(A: torch.Tensor, fmt: str = "mxfp4") -> QuantizedActiva
 def mul_mxfp4_native(A, B, s, global_scale, size_m, size_n, size_k, solution_id=SOLUTION_AUTO_NATIVE_MXFP4, bias=None, activation=None,
                      out_quantized=None):
     """The native-FP4 class with its hand-over points (petit_gemm_mxfp4_native).  A: a 16-bit [size_m, size_k] tensor (quantised
-    by the call: two launches) or QuantizedActivations (one launch).  out_quantized 'mxfp8' / 'mxfp4' (with activation='silu_mul'):
+    by the call: two launches) or QuantizedActivations (one launch).  out_quantized 'mxfp8' / 'mxfp6' / 'mxfp4' (with activation='silu_mul'):
     returns QuantizedActivations [size_m, size_n / 2] for the next GEMM instead of a 16-bit tensor.
-    solution_id: SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4 (-2 / -3) or an explicit native kernel id."""
+    solution_id: SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4 / _MXFP6 (-2 / -3 / -4) or an explicit native kernel id."""
     pre = isinstance(A, QuantizedActivations)
     if pre:
         _check(A.m == size_m and A.k == size_k, f"quantised activations are [{A.m}, {A.k}], the call says [{size_m}, {size_k}]")

@@ -88,7 +88,7 @@ def tune_tensors(A: torch.Tensor, packed, global_scale: torch.Tensor, size_m: in
 def tune(shapes, ms=(1, 2, 4, 8, 16, 32, 64, 128, 256, 512), kind: str = "nvfp4", dtype=torch.bfloat16, path: str = None,
          klass: str = "exact", rotate_mb: int = 1280, device=None, verbose: bool = False) -> list:
     """Tune every (N, K) of `shapes` at every M of `ms` on synthetic weights (random packed bytes: any bytes are a valid weight
-    matrix; scales drawn valid) and record the winners for `solution_id = -1` (klass 'exact') or -2 / -3 (the native class).
+    matrix; scales drawn valid) and record the winners for `solution_id = -1` (klass 'exact') or -2 / -4 / -3 (the native classes: 'native_mxfp8' / 'native_mxfp6' / 'native_mxfp4').
     `path`: also write the rows in the $PETIT_AMD_TUNE_FILE format.  Returns one dict per (shape, M)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     out = []
