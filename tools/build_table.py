@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--ms", default="1,2,4,8,16,32,64,128,256,512")
     ap.add_argument("--out-dir", default=str(ROOT / "gpurun_out" / "r04_table"))
     ap.add_argument("--budget-s", type=float, default=1e9)
+    ap.add_argument("--klass", default="exact", choices=["exact", "native_mxfp8", "native_mxfp6", "native_mxfp4"],
+                    help="the native classes (MXFP4 weights only: --families mx:bf16,mx:f16) fill csrc/tuned_native_gfx950.inc: tools/make_tuned_inc.py --native <out>.tune.txt")
     ap.add_argument("--list", action="store_true", help="print the shape list and exit (no GPU needed)")
     args = ap.parse_args()
     shapes = model_shapes()
@@ -80,7 +82,8 @@ def main():
         return
     out_dir = Path(args.out_dir)
     out_dir.mkdir(parents=True, exist_ok=True)
-    os.environ["PETIT_AMD_TUNE_LOG"] = str(out_dir / f"candidates_{args.part}.csv")
+    tag = args.part if args.klass == "exact" else f"{args.part}_{args.klass}"
+    os.environ["PETIT_AMD_TUNE_LOG"] = str(out_dir / f"candidates_{tag}.csv")
     import torch
 
     import benchlib as BL
@@ -98,7 +101,7 @@ def main():
             for m in ms:
                 g = BL.Gemm(w, m, dtype, dev)
                 try:
-                    sid, us = pk.tune_tensors(g.a, w.packed, g.gs, m, n, k, {"nv": "nvfp4", "mx": "mxfp4"}[fmt], persist=False, samples=5)
+                    sid, us = pk.tune_tensors(g.a, w.packed, g.gs, m, n, k, {"nv": "nvfp4", "mx": "mxfp4"}[fmt], klass=args.klass, persist=False, samples=5)
                 except RuntimeError as exc:
                     print(f"{fam} {n}x{k} M={m}: {exc}", flush=True)
                     continue
@@ -106,11 +109,11 @@ def main():
             del w
             torch.cuda.empty_cache()
             print(f"[{time.time() - t0:6.0f} s] {fam} {n}x{k} done ({len(rows)} rows)", flush=True)
-    with open(out_dir / f"{args.part}.tune.txt", "w") as f:
+    with open(out_dir / f"{tag}.tune.txt", "w") as f:
         f.write("# a_type b_type n k m_lo m_hi solution   (tools/build_table.py; $PETIT_AMD_TUNE_FILE format; us per launch in the json beside it)\n")
         for (at, bt, n, k, m, sid, us) in rows:
             f.write(f"{at} {bt} {n} {k} {m} {m} {sid:x}\n")
-    (out_dir / f"{args.part}.json").write_text(json.dumps({"elapsed_s": time.time() - t0, "rows": [list(r[:5]) + [f"{r[5]:x}", r[6]] for r in rows]}))
+    (out_dir / f"{tag}.json").write_text(json.dumps({"elapsed_s": time.time() - t0, "rows": [list(r[:5]) + [f"{r[5]:x}", r[6]] for r in rows]}))
     print(f"{len(rows)} rows in {time.time() - t0:.0f} s -> {out_dir}")
 
 
