@@ -1232,6 +1232,33 @@ def test_m512_full_size_tiled_and_native(pk, kind, shape):
         pk.ops.enable_native_fp4(False)
 
 
+def test_native_class_table_rows_sampled(pk):
+    """csrc/tuned_native_gfx950.inc beyond the four Llama-3-70B shapes (rows from the in-library tuner over seven model families): a seeded
+    sample of rows per activation format, each run through the class sentinel at the row's shape and M and checked like every native kernel --
+    exact semantics on the CPU-quantised activations, the class tolerance against the unquantised oracle -- and the resolved id IS the row's."""
+    import re
+    rows = re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}", (ROOT / "petit-kernel_amd/csrc/tuned_native_gfx950.inc").read_text())
+    rows = [(int(at), int(n), int(k), int(lo), int(hi), int(sol, 16)) for at, bt, n, k, lo, hi, sol in rows]
+    assert len(rows) > 2000
+    rng = np.random.default_rng(404)
+    sentinels = {2: pk.SOLUTION_AUTO_NATIVE_MXFP8, 4: pk.SOLUTION_AUTO_NATIVE_MXFP6, 6: pk.SOLUTION_AUTO_NATIVE_MXFP4}
+    ran = 0
+    for code, sentinel in sentinels.items():
+        pool = [r for r in rows if (r[5] >> 32) & 7 == code and r[0] == 5 and r[1] * r[2] <= 160e6 and (r[1], r[2]) not in LLAMA70B.values()]
+        for i in rng.choice(len(pool), 3, replace=False):
+            at, n, k, lo, hi, sol = pool[i]
+            m = min(hi, 512)
+            P = FullSizeProblem(pk, "mx", n, k, 7000 + n + k)
+            picked = pk.ops.resolve_solution(P.hints(True), m, n, k, sentinel)
+            assert picked == sol, (n, k, m, hex(picked), hex(sol))
+            a = P.activations(m, True, 7100 + m)
+            check_native_sampled(P, P.run(a, True, sentinel), a, code, f"native table row {n}x{k} M={m} -> {sol:#x}")
+            ran += 1
+            del P
+            torch.cuda.empty_cache()
+    assert ran == 9
+
+
 def test_bench_cells_parity(pk):
     """Every cell bench.py times (tools/benchlib.py bench_cell_plan(): the SAME list) is run here through the same call --
     solution_id -1, or -2 / -3 for the native class -- at full size and checked: zero in -> zero out, one-hot rows read back
