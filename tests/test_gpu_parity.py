@@ -2005,6 +2005,49 @@ def test_prequantized_activations_equal_on_the_fly(pk, m, n, k, fmt, code):
         pk.ops.enable_native_fp4(False)
 
 
+@pytest.mark.parametrize("is_bf16", [True, False])
+@pytest.mark.parametrize("fmt", ["mxfp8", "mxfp6", "mxfp4"])
+def test_activation_quantiser_on_hostile_blocks(pk, fmt, is_bf16):
+    """petit_quantize_activations against its CPU statement on blocks chosen to hit every branch of the rounding: all-zero blocks (scale byte 127),
+    -0.0, one huge value next to tiny ones (everything else flushes or lands in the subnormals), block maxima just below / at / above the
+    saturation point of the element format, exact ties between two codes (round to even), values one ulp either side of a tie, negative twins of
+    all of them, 16-bit subnormals, and blocks whose exponent sits at the ends of the 16-bit type's range."""
+    rng = np.random.default_rng(99)
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    m, k = 16, 2048
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    grid = {"mxfp8": None, "mxfp6": E2M3_GRID, "mxfp4": E2M1_GRID}[fmt]
+    blocks = a.reshape(m, k // 32, 32)
+    blocks[0, 0] = 0.0
+    blocks[0, 1] = -0.0
+    blocks[0, 2, :] = 1e-3
+    blocks[0, 2, 5] = 3.0e4 if is_bf16 else 3.0e3                       # one outlier: the rest of the block is far below a code
+    top = 7.5 if fmt == "mxfp6" else 6.0 if fmt == "mxfp4" else 7.0
+    for j, mx in enumerate((top * 0.999, top, top * 1.03, 7.99, 4.0, 3.999)):   # block maxima around the saturation point (block scale 2^0 .. )
+        blocks[1, j] = rng.uniform(-1, 1, 32)
+        blocks[1, j, 7] = mx
+        blocks[2, j] = -blocks[1, j]
+    if grid is not None:                                                # exact ties and their neighbours, at two block scales
+        mids = (grid[:-1] + grid[1:]) / 2
+        for j, sc in enumerate((1.0, 2.0 ** -9 if not is_bf16 else 2.0 ** -40, 2.0 ** 7)):
+            vals = np.concatenate([mids, mids * (1 + 2.0 ** -7), mids * (1 - 2.0 ** -7)])[:31]
+            blocks[3, j, :31] = 0.0
+            blocks[3, j, :len(vals)] = vals * sc
+            blocks[3, j, 31] = 7.0 * sc                                 # pins the block's scale: maximum in [4, 8) * sc
+            blocks[4, j] = -blocks[3, j]
+    tiny = 2.0 ** -133 if is_bf16 else 2.0 ** -24                       # subnormals of the 16-bit type
+    blocks[5, 0] = tiny * rng.integers(0, 8, 32)
+    blocks[5, 1] = rng.standard_normal(32) * (2.0 ** 120 if is_bf16 else 2.0 ** 14)
+    a = blocks.reshape(m, k)
+    a_bits = O.f32_to_bf16_bits(a) if is_bf16 else a.astype(np.float16).view(np.uint16)
+    x = to_f32(a_bits, is_bf16)
+    want = {"mxfp8": quantize_act_mxfp8, "mxfp6": quantize_act_mxfp6, "mxfp4": quantize_act_mxfp4}[fmt](x)
+    qa = pk.quantize_activations(from_bits(a_bits, dtype).to(DEV), fmt)
+    got = decode_qact(qa.data.cpu().numpy(), m, k, fmt)
+    bad = np.argwhere(got != want)
+    assert bad.size == 0, f"{len(bad)} elements differ; first: row {bad[0][0]} col {bad[0][1]}: x {x[tuple(bad[0])]!r} got {got[tuple(bad[0])]!r} want {want[tuple(bad[0])]!r}"
+
+
 @pytest.mark.parametrize("fmt", ["mxfp8", "mxfp6", "mxfp4"])
 @pytest.mark.parametrize("m,n,k,with_bias", [(64, 512, 1024, False), (130, 1024, 512, True), (512, 1536, 2048, False), (5, 512, 768, False)])
 def test_quantized_silu_mul_output_feeds_the_next_gemm(pk, m, n, k, with_bias, fmt):
