@@ -403,7 +403,8 @@ struct Native32Cfg {
     // MXFP8 fragments are twice the size (the group-ahead double buffer of MB fragments is 64 registers + scales): that form reads its
     // fragments ONE m-block ahead instead (kLean: 18 registers; an FP8-rate MFMA pair covers the LDS latency), which is what lets the
     // 128 x 256 tile fit two workgroups per CU for MXFP8 activations too
-    static constexpr bool kLean = (ACT == 8 || ACT == 6) && WM == 1 && KG == 1 && LW_ == 0 && MB * NP == 8 && D == 2;
+    static constexpr bool kLean = (ACT == 8 || ACT == 6) && WM == 1 && LW_ == 0 &&
+                                  ((KG == 1 && MB * NP == 8 && D == 2) || (ACT == 6 && KG == 2 && WAVES_ == 5)); // (ten waves: 168 registers each)
     static constexpr bool kWantTwoPerSimd = KG == 2 || kLean || (WM == 1 && (ACT == 4 || ACT == 6) && MB * NP == 8 && D == 2);
     static constexpr int kCTileU4 = CTile<BN>::u4(BM);             // the epilogue's image of the C tile (device_common.hpp)
     static constexpr int kRedU4 = KG == 2 ? BM * BN / 4 : 0;       // KG = 2: the second group's accumulators, f32
