@@ -21,9 +21,24 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
     m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 700]))
     if m * n * k > 4e9: continue
     a, q, s, gs = T.random_problem(kind, m, n, k, int(rng.integers(1 << 30)), is_bf16)
-    mode = rng.choice(["auto", "bias", "silu", "fp6", "fp8", "fp4"]) if kind == "mx" else rng.choice(["auto", "bias", "silu"])
+    mode = rng.choice(["auto", "explicit", "explicit", "bias", "silu", "fp6", "fp8", "fp4"]) if kind == "mx" else rng.choice(["auto", "explicit", "explicit", "bias", "silu"])
     try:
-        if mode == "auto":
+        if mode == "explicit":     # a random enumerated kernel of the exact class, with a random K split when the kernel takes one
+            h = pk.PetitSolutionHints()
+            h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+            h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+            sols = pk.ops.get_fp4_solutions(h, m, n, k)
+            sid = int(sols[int(rng.integers(len(sols)))])
+            sk = int(rng.choice([1, 1, 2, 4]))
+            sid_k = (sid & ~(0xF << 60)) | (sk << 60)
+            try:
+                c = T.run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid_k)
+            except RuntimeError:      # (this kernel kind has no such split / K too short)
+                c = T.run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sid)
+                sid_k = sid
+            mode = f"explicit {sid_k:#x}"
+            T.check_gemm(c, T.oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, T.oracle_sum_abs(kind, a, is_bf16, q, s, gs))
+        elif mode == "auto":
             c = T.run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k)
             T.check_gemm(c, T.oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, T.oracle_sum_abs(kind, a, is_bf16, q, s, gs))
         else:
@@ -60,7 +75,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
                 got = T.to_f32(T.bits(c), is_bf16).astype(np.float64)
                 fin = np.isfinite(exact) & (np.abs(exact) < (3e38 if is_bf16 else 6e4))
                 err = np.abs(got - exact)[fin]
-                bound = np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), (2e-5 if fmt == "mxfp8" else 1e-5) * sum_abs)[fin]   # (as the tests)
+                bound = np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), (4e-5 if fmt == "mxfp8" else 1e-5) * sum_abs)[fin]   # (as the tests)
                 assert (err <= bound).all(), (f"native {fmt}: {int((err > bound).sum())} of {err.size} elements over the bound, worst margin err / bound = {(err / bound).max():.2f} "
                                               f"(there: |exact| = {np.abs(exact)[fin][np.argmax(err / bound)]:.3g}, sum|a||w| = {sum_abs[fin][np.argmax(err / bound)]:.3g})")
         n_ok += 1
