@@ -1702,7 +1702,7 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
             # (1) the kernel computes exactly "MXFP8(activations) x MXFP4(weights)": only the f32
             #     accumulation order and the final 16-bit rounding separate it from the oracle.  (4e-5 of sum|a||w| where the terms cancel: the
             #     FP8-rate MFMA aligns the products of a k-group to the largest one -- tools/fuzz_parity.py, profiles/r04_fuzz.txt: 12 elements in
-            #     7 459 random problems between 1.0 and 2.1 x the 1e-5 the other classes keep, each where |result| < sum|a||w| / 400; twice the worst seen.)
+            #     9 854 random problems between 1.0 and 2.1 x the 1e-5 the other classes keep, each where |result| < sum|a||w| / 400; twice the worst seen.)
             err = np.abs(c - exact)[fin]
             assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 4e-5 * sum_abs)[fin]).all()
             # (2) stated tolerance of the path against the UNQUANTISED reference: e4m3 activations carry

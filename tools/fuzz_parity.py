@@ -23,7 +23,26 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
     a, q, s, gs = T.random_problem(kind, m, n, k, int(rng.integers(1 << 30)), is_bf16)
     mode = rng.choice(["auto", "explicit", "explicit", "bias", "silu", "fp6", "fp8", "fp4"]) if kind == "mx" else rng.choice(["auto", "explicit", "explicit", "bias", "silu"])
     try:
-        if mode == "explicit":     # a random enumerated kernel of the exact class, with a random K split when the kernel takes one
+        if m <= 16 and rng.random() < 0.25:    # a grouped launch: 2-4 weight matrices of random N on the same activation rows
+            mode = "grouped"
+            dtype = torch.bfloat16 if is_bf16 else torch.float16
+            ad = T.from_bits(a, dtype).to("cuda")
+            members, refs = [], []
+            for j in range(int(rng.integers(2, 5))):
+                nj = int(rng.choice(Ns))
+                if kind == "mx" and nj % 32: nj += 16
+                _, qj, sj, gsj = T.random_problem(kind, 1, nj, k, int(rng.integers(1 << 30)), is_bf16)
+                qd = torch.from_numpy(qj).to("cuda")
+                if kind == "nv":
+                    bj, spj = pk.repack_nvfp4(qd.view(torch.int32), nj, k), pk.process_nvfp4_scales(torch.from_numpy(sj).to("cuda").view(torch.float8_e4m3fn), nj, k)
+                else:
+                    bj, spj = pk.repack_mxfp4(qd.view(torch.int32), nj, k), pk.process_mxfp4_scales(torch.from_numpy(sj).to("cuda"), nj, k)
+                members.append((bj, spj, torch.tensor([gsj], dtype=torch.float32, device="cuda"), nj))
+                refs.append((T.oracle_ref(kind, a, is_bf16, qj, sj, gsj), T.oracle_sum_abs(kind, a, is_bf16, qj, sj, gsj)))
+            outs = pk.mul_fp4_a16_grouped("nvfp4" if kind == "nv" else "mxfp4", ad, members, m, k, -1)
+            for c, (ref, sa) in zip(outs, refs):
+                T.check_gemm(T.bits(c), ref, is_bf16, sa)
+        elif mode == "explicit":     # a random enumerated kernel of the exact class, with a random K split when the kernel takes one
             h = pk.PetitSolutionHints()
             h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
             h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
