@@ -155,16 +155,16 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
                 r = blk.time(mode[4:], stream)
                 pk_peak = BL.BF16_PEAK_TFLOPS if mode == "mlp_exact" else BL.FP8_PEAK_TFLOPS if "mxfp8" in mode else BL.FP4_PEAK_TFLOPS
                 out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "TF": round(r["tflops"], 1), "frac": round(r["tflops"] / pk_peak, 4)})
-            elif mode == "hipblaslt":
+            elif mode in ("hipblaslt", "hipblaslt_fp8"):
                 weights.clear()
                 torch.cuda.empty_cache()
-                hb = BL.HipblasLtGemm(m, n, k, dtype, dev)
+                hb = BL.HipblasLtGemm(m, n, k, torch.float8_e4m3fn if mode == "hipblaslt_fp8" else dtype, dev)
                 hb.check()
                 rr = hb.time(stream, reps=5)
                 hb.close()
                 del hb
                 out.update({"us": round(rr["us"], 2), "us_min": round(rr["us_min"], 2), "TF": round(rr["tflops"], 1),
-                            "frac": round(rr["tflops"] / BL.BF16_PEAK_TFLOPS, 4)})
+                            "frac": round(rr["tflops"] / (BL.FP8_PEAK_TFLOPS if mode == "hipblaslt_fp8" else BL.BF16_PEAK_TFLOPS), 4)})
             else:
                 if (shape, w) not in weights:
                     weights.clear()
@@ -189,7 +189,7 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
     return {"cells": cells, "cells_notes": notes, "cells_seconds": round(time.time() - t0, 1),
             "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, median of 5-7 replays; "
                             "rate = GB/s (M <= 16) or TFLOP/s; frac = rate / 8000 GB/s, or / 2500 TFLOP/s (native_mxfp8 / 5000, native_mxfp6 and native_mxfp4 / 10000, "
-                            "both launches timed); hipblaslt = vendor dense bf16 GEMM (HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm); "
+                            "both launches timed); hipblaslt = vendor dense bf16 GEMM (HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm), hipblaslt_fp8 = its e4m3 x e4m3 -> bf16 GEMM (/ 5000); "
                             "us_min, kernel id and description per cell: gpurun_out/bench_cells_full.json"}
 
 

@@ -28,7 +28,7 @@ for s in shapes:
                                    for dt, m in cols) + " |")
 print("\nM = 512 (TFLOP/s; fraction of 2.5 PF bf16 peak, native: of the 5 / 10 PF FP8 / FP4 peaks; native cells include the activation-quantiser launch):\n")
 cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("fp16xmx", "fp16 x MXFP4"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"), ("bf16xmx native_mxfp6", "native, act -> MXFP6 (-4)"),
-        ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xdense hipblaslt", "hipBLASLt bf16 dense")]
+        ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xdense hipblaslt", "hipBLASLt bf16 dense"), ("fp8xdense hipblaslt_fp8", "hipBLASLt FP8 dense")]
 print("| shape | " + " | ".join(name for _, name in cols) + " |")
 print("|---|" + "---|" * len(cols))
 for s in shapes:

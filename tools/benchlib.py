@@ -37,7 +37,8 @@ LLAMA70B = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "
 # dtype, fp16 x NVFP4, tools/benchmarks/matmul.py:92-127), in the order bench.py measures it.  tests/test_gpu_parity.py::
 # test_bench_cells_parity iterates the SAME list, so every (shape, M, dtype, mode) that is timed is also checked against the oracle.
 #   mode: "auto" = solution_id -1; "native_mxfp8" / "native_mxfp6" / "native_mxfp4" = the opt-in native class through its own default pick;
-#   "hipblaslt" = the vendor's dense 16-bit GEMM on a dense weight of the same shape (comparator, no parity to check)
+#   "hipblaslt" = the vendor's dense 16-bit GEMM on a dense weight of the same shape (comparator, no parity to check);
+#   "hipblaslt_fp8" = the vendor's FP8 (e4m3 x e4m3 -> bf16) GEMM on the same shape: what the native class competes with
 SHAPE_ORDER = ("qkv", "o", "gate_up", "down")
 
 
@@ -56,7 +57,7 @@ def bench_cell_plan() -> list:
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"), dict(shape=shape, M=512, a="fp16", w="mx", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp6"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
-                 dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt")]
+                 dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=512, a="fp8", w="dense", mode="hipblaslt_fp8")]
     # launch-gap-bound shapes: the q / k / v shards of a TP-8 deployment (1280 x 8192 each) as three launches and as one grouped launch
     plan += [dict(shape="tp8_qkv_3x1280", M=m, a="bf16", w="nv", mode=mode) for m in (1, 16) for mode in ("separate", "grouped")]
     # the gated-MLP block (gate_up -> SiLU-mul -> down) as a unit: what the quantising epilogue buys the native class
@@ -289,13 +290,14 @@ class HipblasLtGemm:
             lib.hbl_destroy.argtypes = [C.c_void_p]
             HipblasLtGemm._lib = lib
         self.m, self.n, self.k = m, n, k
-        self.h = HipblasLtGemm._lib.hbl_create(m, n, k, int(dtype == torch.bfloat16))
+        fp8 = dtype == torch.float8_e4m3fn          # (the vendor's 8-bit GEMM: e4m3 operands, unit scales, bf16 output)
+        self.h = HipblasLtGemm._lib.hbl_create(m, n, k, 2 if fp8 else int(dtype == torch.bfloat16))
         if not self.h:
             raise RuntimeError("hipBLASLt: no algorithm")
-        copies = int(max(2, min(max_copies, (rotate_mb << 20) // (n * k * 2) + 2)))
+        copies = int(max(2, min(max_copies, (rotate_mb << 20) // (n * k * (1 if fp8 else 2)) + 2)))
         self.w = [torch.randn((n, k), device=dev, dtype=torch.float32).to(dtype) for _ in range(copies)]
         self.a = torch.randn((m, k), device=dev, dtype=torch.float32).to(dtype)
-        self.c = torch.empty((m, n), dtype=dtype, device=dev)
+        self.c = torch.empty((m, n), dtype=torch.bfloat16 if fp8 else dtype, device=dev)
 
     def launch(self, i):
         w = self.w[i % len(self.w)]

@@ -32,17 +32,19 @@ struct Gemm {
 
 extern "C" {
 
-// is_bf16: 1 = bf16 operands and output, 0 = fp16.  Returns an opaque handle or NULL.
+// is_bf16: 1 = bf16 operands and output, 0 = fp16, 2 = FP8 (OCP e4m3) operands with a bf16 output (the vendor's 8-bit GEMM: what the
+// native class's block-scaled MFMA path is up against; no scale pointers: unit scales).  Returns an opaque handle or NULL.
 void *hbl_create(int m, int n, int k, int is_bf16) {
     Gemm *g = new Gemm;
-    const hipDataType t = is_bf16 ? HIP_R_16BF : HIP_R_16F;
+    const hipDataType t = is_bf16 == 2 ? HIP_R_8F_E4M3 : is_bf16 ? HIP_R_16BF : HIP_R_16F;
+    const hipDataType tc = is_bf16 ? HIP_R_16BF : HIP_R_16F;
     const hipblasOperation_t trans = HIPBLAS_OP_T;
     HBL_TRY(hipblasLtCreate(&g->handle));
     HBL_TRY(hipblasLtMatmulDescCreate(&g->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
     HBL_TRY(hipblasLtMatmulDescSetAttribute(g->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &trans, sizeof(trans)));
     HBL_TRY(hipblasLtMatrixLayoutCreate(&g->lw, t, k, n, k)); // W row-major [n][k] = column-major k x n
     HBL_TRY(hipblasLtMatrixLayoutCreate(&g->la, t, k, m, k)); // A row-major [m][k] = column-major k x m
-    HBL_TRY(hipblasLtMatrixLayoutCreate(&g->lc, t, n, m, n)); // C row-major [m][n] = column-major n x m
+    HBL_TRY(hipblasLtMatrixLayoutCreate(&g->lc, tc, n, m, n)); // C row-major [m][n] = column-major n x m
     if (hipMalloc(&g->workspace, kWorkspace) != hipSuccess)
         return nullptr;
     g->workspace_bytes = kWorkspace;
