@@ -69,6 +69,11 @@ class Sampler(threading.Thread):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nv-solution", default="", help="run ONLY bf16 x NVFP4 with this explicit kernel id (hex): for ablation libraries ($PETIT_AMD_LIB, tools/ablate_wide.sh)")
+    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "power_probe.json"))
+    args = ap.parse_args()
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(dev)
     power, freq, cap = find_sensors()
@@ -96,17 +101,25 @@ def main():
     n, k, m = 57344, 8192, 512
     flops = 2.0 * m * n * k
     cases = []
-    for fmt, dt in (("nv", torch.bfloat16), ("mx", torch.bfloat16)):
+    if args.nv_solution:
+        w = BL.Weights("nv", n, k, 1280, dev)
+        g = BL.Gemm(w, m, torch.bfloat16, dev)
+        sid = int(args.nv_solution, 16)
+        from petit_kernel import _lib as _l
+        cases.append((f"bf16 x nvfp4 {_l.describe_solution(sid)[:60]}", g, sid))
+    for fmt, dt in (() if args.nv_solution else (("nv", torch.bfloat16), ("mx", torch.bfloat16))):
         w = BL.Weights(fmt, n, k, 1280, dev)
         g = BL.Gemm(w, m, dt, dev)
         cases.append((f"bf16 x {fmt}fp4 default", g, None))
     from petit_kernel import _lib
-    wmx = BL.Weights("mx", n, k, 1280, dev)
-    for name, sent in (("native mxfp6", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6), ("native mxfp4", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), ("native mxfp8", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)):
-        g = BL.Gemm(wmx, m, torch.bfloat16, dev)
-        cases.append((name, g, sent))
-    hb = BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev, 1280)
-    for name, g, sent in cases + [("hipBLASLt bf16 dense", hb, None)]:
+    extra = []
+    if not args.nv_solution:
+        wmx = BL.Weights("mx", n, k, 1280, dev)
+        for name, sent in (("native mxfp6", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6), ("native mxfp4", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), ("native mxfp8", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)):
+            g = BL.Gemm(wmx, m, torch.bfloat16, dev)
+            cases.append((name, g, sent))
+        extra = [("hipBLASLt bf16 dense", BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev, 1280), None)]
+    for name, g, sent in cases + extra:
         if isinstance(g, BL.HipblasLtGemm):
             launch = g.launch
         else:
@@ -149,7 +162,7 @@ def main():
         out["runs"].append(rec)
         time.sleep(1.0)
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
-    (ROOT / "gpurun_out" / "power_probe.json").write_text(json.dumps(out, indent=1))
+    Path(args.out).write_text(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
