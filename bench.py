@@ -129,7 +129,7 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
             notes.append(f"time budget reached before {shape} M={m} {a}x{w} {mode}")
             break
         dtype = torch.bfloat16 if a == "bf16" else torch.float16
-        hbm = m <= 16
+        hbm = m <= BL.HBM_BOUND_MAX_M
         out = {"shape": shape, "M": m, "dt": f"{a}x{w}" + ("" if mode == "auto" else f" {mode}")}
         if shape in BL.LLAMA70B:
             n, k = BL.LLAMA70B[shape]
@@ -188,7 +188,7 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
         torch.cuda.empty_cache()
     return {"cells": cells, "cells_notes": notes, "cells_seconds": round(time.time() - t0, 1),
             "cells_method": "tools/benchlib.py: HIP-graph replay, weights rotated over >= 1.28 GB, >= 20 ms warm-up, median of 5-7 replays; "
-                            "rate = GB/s (M <= 16) or TFLOP/s; frac = rate / 8000 GB/s, or / 2500 TFLOP/s (native_mxfp8 / 5000, native_mxfp6 and native_mxfp4 / 10000, "
+                            "rate = GB/s (M <= 64) or TFLOP/s; frac = rate / 8000 GB/s, or / 2500 TFLOP/s (native_mxfp8 / 5000, native_mxfp6 and native_mxfp4 / 10000, "
                             "both launches timed); hipblaslt = vendor dense bf16 GEMM (HIPBLAS_COMPUTE_32F, TRANSA=T, first heuristic algorithm), hipblaslt_fp8 = its e4m3 x e4m3 -> bf16 GEMM (/ 5000); "
                             "us_min, kernel id and description per cell: gpurun_out/bench_cells_full.json"}
 
@@ -197,19 +197,26 @@ COPY_CEILING_GBS = 6290.0      # the guide's measured HBM copy ceiling (MI355X_M
 
 
 def compact_cells(cells: list) -> dict:
-    """The line's form of the cell table: one short row per cell, and the metric's own 16 cells (bf16 x NVFP4, M in {1, 8, 16, 512},
-    the four Llama-3-70B linears) once more as `metric_cells` -- printed LAST, so that a record which keeps only the tail of stdout
-    keeps them."""
-    rows, metric = [], []
+    """The line's form of the cell table (the driver's record keeps ~8 KB of it): per (shape, dtypes mode) ONE row [shape, "dtypes mode", [us per M],
+    [rate per M]] over the M list `cells_m["dtypes mode"]` (rate = GB/s up to M = 64, TFLOP/s above; the fraction of the roofline is rate / the peak
+    named in cells_method), and the metric's own 16 cells (bf16 x NVFP4, M in {1, 8, 16, 512}, the four Llama-3-70B linears) once more in full as
+    `metric_cells` -- printed LAST, so that a record which keeps only the tail of stdout keeps them."""
+    grouped, ms, metric = {}, {}, []
     for c in cells:
         rate = c.get("GBs", c.get("TF"))
-        rows.append([c["shape"], c["M"], c["dt"], c["us"], rate, round(c["frac"], 3)])
+        ms.setdefault(c["dt"], [])
+        if c["M"] not in ms[c["dt"]]:
+            ms[c["dt"]].append(c["M"])
+        grouped.setdefault((c["shape"], c["dt"]), {})[c["M"]] = (round(c["us"], 1 if c["us"] >= 100 else 2), int(round(rate)))   # (the side file keeps every digit)
         if c["dt"] == "bf16xnv" and c["M"] in (1, 8, 16, 512) and c["shape"] in ("qkv", "o", "gate_up", "down"):
             row = [c["shape"], c["M"], c["us"], rate, round(c["frac"], 3)]
             if "GBs" in c:
                 row.append(round(c["GBs"] / COPY_CEILING_GBS, 3))
             metric.append(row)
-    return {"cells_cols": ["shape", "M", "dtypes mode", "us", "GB/s (M<=16) | TFLOP/s", "frac of 8 TB/s | MFMA peak"], "cells": rows,
+    rows = []
+    for (shape, dt), by_m in grouped.items():
+        rows.append([shape, dt, [by_m[m][0] if m in by_m else None for m in ms[dt]], [by_m[m][1] if m in by_m else None for m in ms[dt]]])
+    return {"cells_cols": ["shape", "dtypes mode", "us per M of cells_m[dtypes mode]", "GB/s (M<=64) | TFLOP/s per M"], "cells_m": ms, "cells": rows,
             "metric_cells_cols": ["shape", "M", "us", "GB/s (M<=16) | TFLOP/s", "frac of 8 TB/s | 2.5 PFLOP/s",
                                   "frac of the 6.29 TB/s copy ceiling (M<=16)"],
             "metric_cells": metric}
@@ -242,7 +249,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cells", action="store_true", help="headline only (skip the M x shape table)")
     ap.add_argument("--no-host-overhead", action="store_true", help="skip the eager host-cost measurement (profiling runs)")
-    ap.add_argument("--cells-budget-s", type=float, default=170.0)
+    ap.add_argument("--cells-budget-s", type=float, default=420.0)
     ap.add_argument("--verbose", action="store_true", help="one stderr line per cell (the kernel each call resolved to)")
     ap.add_argument("--cells-child", default="", help=argparse.SUPPRESS)   # internal: run the cell table, append JSON lines to this file
     ap.add_argument("--rotate-mb", type=int, default=1280,

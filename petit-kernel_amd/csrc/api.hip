@@ -158,6 +158,37 @@ bool act_runs(const SolutionEntry &e, unsigned splitk, unsigned restrict_ = 0) {
     return splitk > 1 ? !(restrict_ & kNeedQuantOut) : act_ok(e);
 }
 
+// The workgroup tile of a kernel (rows x columns of C), whatever its kind (solution.h: the fields read differently per kind).
+void entry_tile(const SolutionEntry &e, unsigned *bm, unsigned *bn) {
+    const StreamShape &s = e.shape;
+    const bool m32 = s.am == kWideAm || s.am == kNative32Am; // 32-row MFMA blocks: tile_m counts m32-blocks
+    *bm = (m32 ? 32u : 16u) * (unsigned)s.mt;
+    *bn = 16u * (unsigned)s.wn * (unsigned)s.nt;
+}
+uint64_t operand_bytes(const SolutionEntry &e, unsigned m, unsigned n, unsigned k) {
+    return (uint64_t)n * k / 2 + (uint64_t)n * k / (e.fmt == kFmtNv ? 16 : 32) + 2ull * m * k + 2ull * m * n;
+}
+// The K split a (kernel, problem) may run with, given the split a table row / the caller's bucket asks for.  A row is measured at ONE M and
+// serves a bucket (the last one open-ended): a split that filled the chip at M = 512 is pure overhead at M = 16375 -- the unsplit grid already
+// covers the chip several times, and the fp32 slabs (splitk * m * n * 4 bytes, written and read once more by the reduce pass) outgrow the
+// operands.  Rules:
+//   * no split once the unsplit grid has >= 2 workgroups per CU;
+//   * halve the split while its slabs are larger than everything the GEMM reads and writes (W + scales + A + C).
+// tune_candidates applies the same rule, so a tuned row never names a split this function would take away at the M it was measured at.
+unsigned guarded_splitk(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k, int num_cus) {
+    if (splitk <= 1)
+        return splitk;
+    unsigned bm, bn;
+    entry_tile(e, &bm, &bn);
+    const uint64_t tiles = (uint64_t)((m + bm - 1) / bm) * ((n + bn - 1) / bn);
+    if (tiles >= 2ull * (unsigned)num_cus)
+        return 1;
+    const uint64_t cap = operand_bytes(e, m, n, k);
+    while (splitk > 1 && splitk_bytes(splitk, m, n) > cap)
+        splitk >>= 1;
+    return splitk;
+}
+
 // M > 16: a cost model calibrated on the r01 sweeps (profiles/r01_tune_midm_*.json, r01_tune_bigm_*.json; microseconds
 // on MI355X, bf16 x NVFP4; the other families scale uniformly, which does not change the argmin much):
 //  * streaming kernel, MT m-tiles per workgroup, NT n-tiles per wave: every 16*MT-row block repeats the unpack and
@@ -256,7 +287,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
                           //  cost model is good to ~10 % per kernel, and an argmin over twice the candidates loses more to that noise than it gains)
             double us;
             unsigned sk = 1;
-            if (s.am == kTiledAm || s.am == kWideAm) {
+            if (s.am == kTiledAm) { // (the 32x32 kernels were skipped above: they reach the default path through the arch table and its neighbours)
                 us = tiled_cost_us(e, m, n, k, arch.num_cus);
                 if (splitk_out) { // (SiLU-mul too: the reduce pass applies it) K-heavy / narrow problems leave most CUs idle without a K split
                     for (unsigned cand = 2; cand <= 8 && cand <= nspans; cand *= 2) {
@@ -465,6 +496,24 @@ bool nearest_disabled() { // $PETIT_AMD_NO_NEAREST=1: unseen shapes go straight 
     }();
     return off;
 }
+// $PETIT_AMD_NEAREST_K=1: an unseen shape takes the nearest tabulated shape's kernel blindly (round 4's behaviour; tools/check_heuristic.py compares)
+int nearest_k() {
+    static const int v = [] {
+        const char *e = getenv("PETIT_AMD_NEAREST_K");
+        const long x = e && *e ? strtol(e, nullptr, 10) : 3;
+        return (int)(x < 1 ? 1 : x > 8 ? 8 : x);
+    }();
+    return v;
+}
+// a farther neighbour's kernel replaces a nearer one's only when the cost model puts it this far ahead (the model's own error is 6-9 % per kernel; 0.85 from a sweep over the held-out shapes, profiles/r05_heuristic.md)
+double nearest_switch_gain() { // $PETIT_AMD_NEAREST_GAIN overrides (tools/check_heuristic.py sweeps it)
+    static const double v = [] {
+        const char *e = getenv("PETIT_AMD_NEAREST_GAIN");
+        const double x = e && *e ? strtod(e, nullptr) : 0.0;
+        return x > 0.0 && x <= 1.0 ? x : 0.85;
+    }();
+    return v;
+}
 AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k,
                        int klass = kClassExact, unsigned restrict_ = 0) {
     struct Slot {
@@ -490,20 +539,52 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
             c.entry = nullptr;
     }
     if (!c.entry && !nearest_disabled()) {
-        // no row for this shape: the row of the nearest tabulated shape (hal.h tuned_nearest), when its kernel can run this problem
-        const uint64_t near = tuned_nearest(dev, a_type, b_type, m, n, k, klass, kNearestMaxDistance);
-        if (near) {
-            c.entry = find_entry(fam, near);
-            c.splitk = solution_splitk(near);
-            const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
-            if (c.entry && (entry_class(*c.entry) != klass || !entry_fits(*c.entry, m, k) || c.splitk == 0 || c.splitk > nspans ||
-                            (act && !act_runs(*c.entry, c.splitk, restrict_)) || !entry_allows(*c.entry, restrict_)))
-                c.entry = nullptr;
+        // no row for this shape: the rows of the nearest tabulated shapes (hal.h tuned_nearest_list) whose kernels can run this problem.  The
+        // nearest one wins unless the fitted cost model (tiled_cost_us: the large-M kernels, 6-9 % median error) can price BOTH it and a farther
+        // neighbour's kernel on THIS problem's grid and the farther one comes out clearly ahead -- a neighbour's winner was chosen for how ITS N
+        // and M fill the chip in whole rounds, which does not transfer (held-out shapes, profiles/r05_heuristic.md).
+        constexpr int kNeighbours = 3;
+        TunedNeighbour nb[kNeighbours];
+        const int found = tuned_nearest_list(dev, a_type, b_type, m, n, k, klass, kNearestMaxDistance, nb, nearest_k() < kNeighbours ? nearest_k() : kNeighbours);
+        const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+        const int num_cus = arch_info(dev).num_cus;
+        double best_us = 0.0;
+        for (int i = 0; i < found; ++i) {
+            const SolutionEntry *e = find_entry(fam, nb[i].solution);
+            unsigned sk = solution_splitk(nb[i].solution);
+            if (!e || entry_class(*e) != klass || !entry_fits(*e, m, k) || sk == 0 || sk > nspans || (act && !act_runs(*e, sk, restrict_)) ||
+                !entry_allows(*e, restrict_))
+                continue;
+            sk = guarded_splitk(*e, sk, m, n, k, num_cus);
+            if (act && !act_runs(*e, sk, restrict_))
+                continue;
+            const bool priced = klass == kClassExact && (e->shape.am == kTiledAm || e->shape.am == kWideAm) && !is_shared(*e) && step_cost(*e) != nullptr;
+            const double us = priced ? tiled_cost_us(*e, m, n, k, num_cus, sk) : 0.0;
+            if (!c.entry) { // the nearest runnable neighbour
+                c.entry = e, c.splitk = sk, best_us = us;
+                if (!priced || nb[i].distance == 0.0)
+                    break; // nothing to compare with (the streaming / decode kernels have no fitted model), or not a neighbour at all
+            } else if (priced && us < nearest_switch_gain() * best_us) {
+                c.entry = e, c.splitk = sk, best_us = us;
+            }
         }
     }
     if (!c.entry)
         c.entry = klass == kClassExact ? heuristic(fam, m, n, k, act, &c.splitk)
                                        : heuristic_native(fam, klass, m, n, k, act, true, &c.splitk, restrict_);
+    if (c.entry && c.splitk > 1) {
+        // a row serves a whole M bucket: the split it was measured with is kept only while it still makes sense at THIS m (guarded_splitk)
+        const unsigned sk = guarded_splitk(*c.entry, c.splitk, m, n, k, arch_info(dev).num_cus);
+        if (sk != c.splitk && act && !act_runs(*c.entry, sk, restrict_)) {
+            // SiLU-mul rode on the reduce pass of the split that just went away: a kernel whose own epilogue does it
+            unsigned sk2 = 1;
+            c.entry = klass == kClassExact ? heuristic(fam, m, n, k, true, nullptr)
+                                           : heuristic_native(fam, klass, m, n, k, true, false, &sk2, restrict_);
+            c.splitk = 1;
+        } else {
+            c.splitk = sk;
+        }
+    }
     slot = Slot{key0, key1, generation, c};
     return c;
 }
@@ -582,6 +663,7 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
     if (!family_for(a_type, b_type, &fam) || !shape_ok(n, k) || m == 0 || (klass != kClassExact && b_type != kDataTypeMxFp4e2m1))
         return 0; // (the native class exists for MXFP4 weights only)
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    const int num_cus = arch_info(current_device()).num_cus;
     int count = 0;
     auto push = [&](const SolutionEntry &e, unsigned sk, bool front) {
         const uint64_t need = workspace_need(e, sk, m, n, k);
@@ -613,7 +695,8 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         if (!splittable)
             continue;
         for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)
-            push(e, sk, false);
+            if (guarded_splitk(e, sk, m, n, k, num_cus) == sk) // (a row must never name a split that choose_auto would take away again)
+                push(e, sk, false);
     }
     return count;
 }
@@ -648,6 +731,10 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     // 32-bit buffer offsets inside one n-tile row / activation block
     if ((uint64_t)k * 16 * 4 * 2 >= (1ull << 31) || (uint64_t)k * 64 * 4 >= (1ull << 31))
         return kErrProblemShape;
+    // M: every kernel addresses A and C per workgroup (64-bit base + a 32-bit offset inside at most 256 rows), so the exact kernels take any M
+    // up to the tables' last bucket (prefill chunks of 16375 x 57344 included); beyond it, refuse rather than wrap a grid dimension
+    if (m > kMaxM)
+        return kErrProblemShape;
     // the native pipeline: pre-quantised activations / quantised SiLU-mul output (MXFP4 weights, 32x32x64 kernels only)
     const unsigned restrict_ = (a_format ? kNeedK32 : 0u) | (out_format ? kNeedQuantOut : 0u);
     if (restrict_ && b_type != kDataTypeMxFp4e2m1)
@@ -674,6 +761,10 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     }
     if (klass != kClassExact && b_type != kDataTypeMxFp4e2m1)
         return kErrKernelShape; // the native class exists for MXFP4 weights only (e4m3 group scales are not E8M0 block scales)
+    // the native kernels read the quantised activations (k-tile major, up to m * k bytes) through ONE 32-bit buffer descriptor, and the
+    // quantiser's grid has one row per activation row
+    if ((klass != kClassExact || a_format) && ((uint64_t)m * k >= (1ull << 32) || m > 65535u))
+        return kErrProblemShape;
     if (restrict_ && is_auto && klass == kClassExact)
         return kErrKernelShape; // quantised I/O is the native class's: name it (a sentinel or an explicit native id)
     if (a_format && klass != kClassExact && (unsigned)klass != a_format)
@@ -713,6 +804,9 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
             return kErrKernelShape;
     }
 
+    if (is_native_am(entry->shape.am) && ((uint64_t)m * k >= (1ull << 32) || m > 65535u))
+        return kErrProblemShape; // (an explicit native id: the same descriptor range as above)
+
     GemmArgs args{};
     args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
     args.m = m, args.n = n, args.k = k;
@@ -734,7 +828,16 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         }
         if (!ws && klass != kClassExact && is_auto && splitk > 1) {
             // native default pick with a K split, scratch (per call or registered) covers the activations only, or they came quantised: the
-            // same kernel unsplit -- what petit_gemm_resolve_solution reports for the same arguments
+            // same kernel unsplit -- what petit_gemm_resolve_solution reports for the same arguments.  SiLU-mul rode on the reduce pass of
+            // the split (act_runs): unsplit it is the kernel's own epilogue's job, which needs gate and up tile in one wave (act_ok) -- a
+            // row like the 64 x 320 kernel (five n-tiles per wave) x split 4 cannot, and returned kOk with C unwritten: re-pick
+            if (act && !act_ok(*entry)) {
+                unsigned sk1 = 1;
+                const SolutionEntry *e1 = heuristic_native(fam, klass, m, n, k, true, /*have_slabs=*/false, &sk1, restrict_);
+                if (!e1)
+                    return kErrKernelShape;
+                entry = e1;
+            }
             const uint64_t need1 = workspace_need(*entry, 1, m, n, k, have_qa);
             void *ws1 = nullptr;
             if (!need1) {
@@ -767,11 +870,19 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     if (rc == kErrSplitCollapsed) {
         // K is too short for the split the id (or the table row) names: the kernel runs as one part, so SiLU-mul is its own epilogue's job
         if (!act_ok(*entry)) {
-            if (!is_auto || klass != kClassExact)
+            if (!is_auto)
                 return kErrKernelShape;
-            entry = heuristic(fam, m, n, k, true);
-            if (!entry || workspace_need(*entry, 1, m, n, k))
-                return kErrKernelShape;
+            if (klass != kClassExact) { // native class: the class's best kernel whose own epilogue applies SiLU-mul, within the scratch at hand
+                unsigned sk1 = 1;
+                const SolutionEntry *e1 = heuristic_native(fam, klass, m, n, k, true, /*have_slabs=*/false, &sk1, restrict_);
+                if (!e1 || workspace_need(*e1, 1, m, n, k, have_qa) > workspace_need(*entry, splitk, m, n, k, have_qa))
+                    return kErrKernelShape;
+                entry = e1;
+            } else {
+                entry = heuristic(fam, m, n, k, true);
+                if (!entry || workspace_need(*entry, 1, m, n, k))
+                    return kErrKernelShape;
+            }
         }
         args.act = 1u, args.reduce_act = 0u;
         rc = entry->launch(args, 1, (hipStream_t)stream);
@@ -1022,12 +1133,18 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
     AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, klass);
     if (ch.entry && workspace_need(*ch.entry, ch.splitk, m, n, k) > workspace_bytes) {
         // exactly what gemm_impl does when the caller's scratch does not cover the pick
-        if (klass == kClassExact)
+        if (klass == kClassExact) {
             ch.entry = heuristic(fam, m, n, k, act), ch.splitk = 1;
-        else if (workspace_need(*ch.entry, 1, m, n, k) <= workspace_bytes)
-            ch.splitk = 1;
-        else
-            ch.entry = nullptr;
+        } else {
+            if (act && !act_ok(*ch.entry)) { // (unsplit, SiLU-mul is the kernel's own epilogue's: gemm_impl re-picks the same way)
+                unsigned sk1 = 1;
+                ch.entry = heuristic_native(fam, klass, m, n, k, true, /*have_slabs=*/false, &sk1);
+            }
+            if (ch.entry && workspace_need(*ch.entry, 1, m, n, k) <= workspace_bytes)
+                ch.splitk = 1;
+            else
+                ch.entry = nullptr;
+        }
     }
     return ch.entry ? make_solution_id(ch.entry->shape, fam.elem_b, entry_mfma(fam, *ch.entry), ch.splitk) : 0;
 }

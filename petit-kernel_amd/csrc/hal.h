@@ -53,6 +53,14 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
 // the neighbour's kernel is within 1 % of the best kernel in the median, 14 % at the 90th percentile; the formula-based heuristic 5 % / 24 %.
 uint64_t tuned_nearest(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, unsigned *n_found = nullptr,
                        unsigned *k_found = nullptr);
+// The `cap` nearest tabulated shapes (one entry per shape, nearest first, each with the row that holds m), for callers that want to rank them:
+// api.hip choose_auto scores the neighbours' kernels for THIS problem's grid instead of taking the nearest blindly.
+struct TunedNeighbour {
+    uint64_t solution;
+    unsigned n, k;
+    double distance;
+};
+int tuned_nearest_list(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, TunedNeighbour *out, int cap);
 // class of a solution id: 0 exact, 8 / 4 native with MXFP8 / MXFP4 activations
 int solution_class(uint64_t solution);
 // Add (or replace) a row at run time; thread safe; bumps tuned_generation() so cached default picks are re-derived.

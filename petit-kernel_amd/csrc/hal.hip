@@ -10,10 +10,13 @@
 #include <sys/file.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "petit_internal.h"
@@ -80,6 +83,7 @@ std::vector<TunedEntry> g_override;
 std::once_flag g_override_once;
 std::mutex g_rows_mutex;
 std::atomic<uint64_t> g_generation{1};
+std::atomic<size_t> g_override_count{0}; // rows in g_override: the lookups skip the mutex while there are none (the usual case)
 
 // rows written by round 3 may carry b_type 8 / element nibble 3 ("MXFP4 with scales in fp16's range"): plain MXFP4 now (petit_internal.h)
 TunedEntry canonical_row(TunedEntry e) {
@@ -117,6 +121,7 @@ void load_override() {
     std::vector<TunedEntry> rows = read_rows(path);
     std::lock_guard<std::mutex> lock(g_rows_mutex);
     g_override.insert(g_override.end(), rows.begin(), rows.end());
+    g_override_count.store(g_override.size(), std::memory_order_release);
 }
 
 bool same_problem(const TunedEntry &a, const TunedEntry &b) {
@@ -152,6 +157,46 @@ bool matches(const TunedEntry &e, int a_type, int b_type, unsigned m, unsigned n
            solution_class(e.solution) == klass;
 }
 
+// The built-in tables, indexed once: the generator sorts rows by (a_type, b_type, N, K, ...), so the rows of one (dtypes, shape) are one
+// contiguous run.  A lookup is a map probe + a scan of that run (10-13 rows; x3 activation formats in the native table) instead of a scan
+// of 3680 / 2760 rows with the M test last (eager prefill with varying token counts misses the per-thread pick cache on every
+// call, and the miss path cost tens of microseconds next to 10-400 us kernels).  shapes[] also serves the nearest-shape search: one
+// distance per distinct shape, not per row.
+struct ShapeRun {
+    int a_type, b_type;
+    unsigned n, k;
+    const TunedEntry *first, *last; // [first, last)
+};
+struct TableIndex {
+    std::vector<ShapeRun> shapes;
+    std::map<std::tuple<int, int, unsigned, unsigned>, int> by_key;
+    explicit TableIndex(const TunedEntry *rows) {
+        for (const TunedEntry *e = rows; e->solution;) {
+            const TunedEntry *f = e;
+            while (f->solution && f->a_type == e->a_type && f->b_type == e->b_type && f->n == e->n && f->k == e->k)
+                ++f;
+            const auto key = std::make_tuple(e->a_type, e->b_type, e->n, e->k);
+            auto it = by_key.find(key);
+            if (it == by_key.end()) {
+                by_key.emplace(key, (int)shapes.size());
+                shapes.push_back(ShapeRun{e->a_type, e->b_type, e->n, e->k, e, f});
+            } else { // (a hand-edited table whose rows of one shape are not contiguous: never generated, but stay correct -- widen the run)
+                ShapeRun &r = shapes[it->second];
+                r.first = std::min(r.first, e), r.last = std::max(r.last, f);
+            }
+            e = f;
+        }
+    }
+    const ShapeRun *find(int a_type, int b_type, unsigned n, unsigned k) const {
+        const auto it = by_key.find(std::make_tuple(a_type, b_type, n, k));
+        return it == by_key.end() ? nullptr : &shapes[it->second];
+    }
+};
+const TableIndex &builtin_index(int klass) {
+    static const TableIndex exact(kBuiltin), native(kBuiltinNative);
+    return klass == 0 ? exact : native;
+}
+
 } // namespace
 
 const ArchInfo &arch_info(int device) {
@@ -176,6 +221,7 @@ void tuned_insert(const TunedEntry &row) {
     {
         std::lock_guard<std::mutex> lock(g_rows_mutex);
         insert_row(g_override, e);
+        g_override_count.store(g_override.size(), std::memory_order_release);
     }
     g_generation.fetch_add(1, std::memory_order_acq_rel);
 }
@@ -226,48 +272,80 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
         return 0;
     b_type = canonical_b_type(b_type);
     std::call_once(g_override_once, load_override);
-    {
+    if (g_override_count.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(g_rows_mutex);
         for (const TunedEntry &e : g_override)
             if (matches(e, a_type, b_type, m, n, k, klass))
                 return e.solution;
     }
-    for (const TunedEntry *e = klass == 0 ? kBuiltin : kBuiltinNative; e->solution; ++e)
-        if (matches(*e, a_type, b_type, m, n, k, klass))
-            return e->solution;
+    if (const ShapeRun *run = builtin_index(klass).find(a_type, b_type, n, k))
+        for (const TunedEntry *e = run->first; e != run->last; ++e)
+            if (matches(*e, a_type, b_type, m, n, k, klass))
+                return e->solution;
     return 0;
 }
 
-uint64_t tuned_nearest(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, unsigned *n_found,
-                       unsigned *k_found) {
-    if (!tuned_lookup_enabled(device) || n == 0 || k == 0)
+int tuned_nearest_list(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, TunedNeighbour *out, int cap) {
+    if (!tuned_lookup_enabled(device) || n == 0 || k == 0 || cap <= 0)
         return 0;
     b_type = canonical_b_type(b_type);
     auto span_class = [](unsigned kk) { return kk % 1024 == 0 ? 8 : kk % 512 == 0 ? 4 : 2; }; // (layout.h span_tiles_for_k: a kernel is built for one)
     const int ks = span_class(k);
-    uint64_t best = 0;
-    double best_d = max_distance;
-    auto consider = [&](const TunedEntry &e) {
-        if (e.a_type != a_type || e.b_type != b_type || m < e.m_lo || m > e.m_hi || solution_class(e.solution) != klass || span_class(e.k) != ks)
+    int count = 0;
+    // keep the `cap` nearest, one per tabulated shape, nearest first (insertion into a tiny sorted array)
+    auto offer = [&](const TunedEntry &e, double d) {
+        for (int i = 0; i < count; ++i)
+            if (out[i].n == e.n && out[i].k == e.k) { // (a run-time row and a built-in row of the same shape: the first offered wins -- run-time rows are offered first)
+                return;
+            }
+        int pos = count;
+        while (pos > 0 && out[pos - 1].distance > d)
+            --pos;
+        if (pos >= cap)
             return;
-        const double d = 2.0 * std::fabs(std::log((double)n / e.n)) + std::fabs(std::log((double)k / e.k));
-        if (d < best_d) {
-            best_d = d, best = e.solution;
-            if (n_found)
-                *n_found = e.n;
-            if (k_found)
-                *k_found = e.k;
-        }
+        for (int i = std::min(count, cap - 1); i > pos; --i)
+            out[i] = out[i - 1];
+        out[pos] = TunedNeighbour{e.solution, e.n, e.k, d};
+        if (count < cap)
+            ++count;
     };
+    auto distance = [&](unsigned en, unsigned ek) { return 2.0 * std::fabs(std::log((double)n / en)) + std::fabs(std::log((double)k / ek)); };
     std::call_once(g_override_once, load_override);
-    {
+    if (g_override_count.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(g_rows_mutex);
-        for (const TunedEntry &e : g_override)
-            consider(e);
+        for (const TunedEntry &e : g_override) {
+            if (e.a_type != a_type || e.b_type != b_type || m < e.m_lo || m > e.m_hi || solution_class(e.solution) != klass || span_class(e.k) != ks)
+                continue;
+            const double d = distance(e.n, e.k);
+            if (d < max_distance)
+                offer(e, d);
+        }
     }
-    for (const TunedEntry *e = klass == 0 ? kBuiltin : kBuiltinNative; e->solution; ++e)
-        consider(*e);
-    return best;
+    for (const ShapeRun &run : builtin_index(klass).shapes) {
+        if (run.a_type != a_type || run.b_type != b_type || span_class(run.k) != ks)
+            continue;
+        const double d = distance(run.n, run.k);
+        if (d >= max_distance || (count == cap && d >= out[count - 1].distance))
+            continue;
+        for (const TunedEntry *e = run.first; e != run.last; ++e)
+            if (m >= e->m_lo && m <= e->m_hi && solution_class(e->solution) == klass) {
+                offer(*e, d);
+                break;
+            }
+    }
+    return count;
+}
+
+uint64_t tuned_nearest(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, unsigned *n_found,
+                       unsigned *k_found) {
+    TunedNeighbour one;
+    if (tuned_nearest_list(device, a_type, b_type, m, n, k, klass, max_distance, &one, 1) == 0)
+        return 0;
+    if (n_found)
+        *n_found = one.n;
+    if (k_found)
+        *k_found = one.k;
+    return one.solution;
 }
 
 } // namespace petit_amd

@@ -40,6 +40,10 @@ enum DataType : int {
 constexpr bool is_mx_type(int b_type) { return b_type == kDataTypeMxFp4e2m1 || b_type == kDataTypeMxFp4e2m1F16Range; }
 constexpr int canonical_b_type(int b_type) { return b_type == kDataTypeMxFp4e2m1F16Range ? (int)kDataTypeMxFp4e2m1 : b_type; }
 
+// the largest M any entry point accepts (PETIT_ERROR_PROBLEM_SHAPE beyond): the open-ended last bucket of the arch tables ends here, and every
+// 32-bit quantity the kernels form from M (grid rows, row * k * 2 inside one workgroup's activation block) stays in range below it
+constexpr unsigned kMaxM = 1u << 20;
+
 struct GemmArgs {
     void *c;            // [m][n] 16-bit, row-major
     const void *a;      // [m][k] 16-bit, row-major

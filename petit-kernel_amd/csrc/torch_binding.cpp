@@ -155,13 +155,17 @@ TORCH_LIBRARY(petit_kernel, m) {
           "Tensor? bias=None, int activation=0) -> Tensor");
     m.def("mul_mxfp4_a16(Tensor A, Tensor B, Tensor s, Tensor global_scale, int size_m, int size_n, int size_k, int solution_id, "
           "Tensor? bias=None, int activation=0) -> Tensor");
+    // round 3's op name (scales promised inside fp16's range): an alias of mul_mxfp4_a16 for one more round -- the kernels test the range themselves
+    m.def("mul_mxfp4_a16_f16range(Tensor A, Tensor B, Tensor s, Tensor global_scale, int size_m, int size_n, int size_k, int solution_id, "
+          "Tensor? bias=None, int activation=0) -> Tensor");
 }
 #define PETIT_IMPL_REAL(m)                                      \
     m.impl("repack_nvfp4", &repack_nvfp4);                      \
     m.impl("process_nvfp4_scales", &process_nvfp4_scales);      \
     m.impl("process_mxfp4_scales", &process_mxfp4_scales);      \
     m.impl("mul_nvfp4_a16", &mul_nvfp4_a16);                    \
-    m.impl("mul_mxfp4_a16", &mul_mxfp4_a16);
+    m.impl("mul_mxfp4_a16", &mul_mxfp4_a16);                    \
+    m.impl("mul_mxfp4_a16_f16range", &mul_mxfp4_a16);
 TORCH_LIBRARY_IMPL(petit_kernel, CUDA, m) { PETIT_IMPL_REAL(m) }
 TORCH_LIBRARY_IMPL(petit_kernel, CPU, m) { PETIT_IMPL_REAL(m) }
 TORCH_LIBRARY_IMPL(petit_kernel, Meta, m) {
@@ -170,4 +174,5 @@ TORCH_LIBRARY_IMPL(petit_kernel, Meta, m) {
     m.impl("process_mxfp4_scales", &process_mxfp4_scales_meta);
     m.impl("mul_nvfp4_a16", &mul_a16_meta);
     m.impl("mul_mxfp4_a16", &mul_a16_meta);
+    m.impl("mul_mxfp4_a16_f16range", &mul_a16_meta);
 }

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -168,12 +169,15 @@ bool env_on(const char *name) {
 } // namespace
 
 void tune_bucket(unsigned m, uint64_t solution, unsigned *m_lo, unsigned *m_hi) {
-    // the M buckets of the built-in table (tools/make_tuned_inc.py): 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, 65-128, 129-256, 257+
+    // the M buckets of the built-in table (tools/make_tuned_inc.py): 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, 65-128, 129-256, 257-512, 513-1024,
+    // 1025-4096, 4097+ (round 5: the prefill buckets above 512 are their own rows -- a pick measured at M = 512 says little about M = 16375)
     unsigned lo = 1, hi = 1;
-    while (hi < m && hi < 256)
+    while (hi < m && hi < 1024)
         lo = hi + 1, hi *= 2;
-    if (m > 256)
-        lo = 257, hi = 1u << 20;
+    if (m > 4096)
+        lo = 4097, hi = kMaxM;
+    else if (m > 1024)
+        lo = 1025, hi = 4096;
     // a kernel that stages at most AM activation rows cannot serve a bucket that reaches past AM: the row covers m alone
     static const int kRowsOfCode[16] = {0, 1, 2, 4, 1, 1, 2, 4, 0, 0, 8, 16, 0, 0, 2, 4};
     int rows = kRowsOfCode[(solution >> 48) & 0xf];
@@ -352,7 +356,8 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
 // caller's own buffers (the output is overwritten by candidates and then by the real call) and the scratch of THAT call (so the winner
 // is a kernel this caller can run).  Everything else -- the reference output, clones of the caller's weights for the rotation -- comes
 // out of the pool reserved with petit_tune_reserve, else from hipMalloc; the run happens with the thread's capture mode relaxed, so a
-// capture in progress on another stream survives it (RelaxedCaptureMode above).  Once per key and process, whatever the outcome.  The
+// capture in progress on another stream survives it (RelaxedCaptureMode above).  Once per key and process for successes and hard failures (a
+// sighting while the caller's own stream is capturing does not count; transient launch / allocation failures get a few retries).  The
 // row lands in the run-time table and, when $PETIT_AMD_TUNE_FILE is set, in that file (merged with what other processes saved, hal.hip
 // tuned_save) for the next process.
 bool autotune_enabled() {
@@ -381,6 +386,13 @@ void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const u
     static std::vector<Key> seen;
     unsigned lo, hi;
     tune_bucket(m, 0, &lo, &hi);
+    // a first sighting INSIDE a stream capture (serving stacks often meet their M buckets while capturing graphs) cannot tune -- and must not
+    // burn the key: the first eager call of the same problem tunes it
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return;
+    }
     {
         std::lock_guard<std::mutex> lock(seen_mutex);
         for (const Key &f : seen)
@@ -390,7 +402,20 @@ void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const u
     }
     uint64_t best = 0;
     float us = 0.f;
-    if (tune_problem(rq, &best, &us) != kOk)
+    const int rc = tune_problem(rq, &best, &us);
+    if (rc == kErrLaunch) {
+        // transient (out of memory for the reference output / the rotation, a device error): give the key a bounded number of further chances
+        static std::atomic<int> retries{8};
+        if (retries.fetch_sub(1) > 0) {
+            std::lock_guard<std::mutex> lock(seen_mutex);
+            for (size_t i = 0; i < seen.size(); ++i)
+                if (seen[i].a_type == a_type && seen[i].b_type == rq.b_type && seen[i].n == n && seen[i].k == k && seen[i].m_lo == lo) {
+                    seen.erase(seen.begin() + (long)i);
+                    break;
+                }
+        }
+    }
+    if (rc != kOk)
         return;
     const char *path = getenv("PETIT_AMD_TUNE_FILE");
     if (path && *path)

@@ -79,9 +79,13 @@ def mul_nvfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scal
 
 def mul_mxfp4_a16(a: torch.Tensor, b: torch.Tensor, s: torch.Tensor, global_scale: torch.Tensor,
                   size_m: int, size_n: int, size_k: int, solution_id: int = -1, *, bias: torch.Tensor = None,
-                  activation: str = None) -> torch.Tensor:
+                  activation: str = None, f16_range: bool = None) -> torch.Tensor:
     # fp16 activations are an extension (the reference's MXFP4 path takes bf16 only, gemm_fp4_fp16_grid.cc:55-64); any negative solution_id
-    # is the library default as in the reference (fp4.cc:240) -- the native class is reached through mul_mxfp4_native only
+    # is the library default as in the reference (fp4.cc:240) -- the native class is reached through mul_mxfp4_native only.
+    # f16_range: round 3's promise "every block scale lies in 114..140"; ignored since round 4 (the kernels test it), accepted for one more round
+    if f16_range is not None:
+        import warnings
+        warnings.warn("mul_mxfp4_a16(f16_range=...) is ignored: the fp16 x MXFP4 kernels test the scale range themselves", DeprecationWarning, stacklevel=2)
     return _impl.mul_mxfp4_a16(a, b, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 

@@ -240,8 +240,13 @@ def mul_nvfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bi
     return _mul("nv", A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias, activation)
 
 
-def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None) -> torch.Tensor:
-    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue."""
+def mul_mxfp4_a16(A, B, s, global_scale, size_m, size_n, size_k, solution_id, bias=None, activation=None, f16_range=None) -> torch.Tensor:
+    """fp4.cc:211-260 (MulMxFp4A16); `bias` / `activation` (optional, not in the reference) are fused into the epilogue.
+    `f16_range` (round 3: "every e8m0 block scale lies in 114..140") is accepted and ignored, with a DeprecationWarning: the fp16 x MXFP4 kernels test
+    the scale range themselves."""
+    if f16_range is not None:
+        import warnings
+        warnings.warn("mul_mxfp4_a16(f16_range=...) is ignored: the fp16 x MXFP4 kernels test the scale range themselves", DeprecationWarning, stacklevel=2)
     _check(B.size(0) == size_n // _LAYOUT_N, f"B.size(0) = {B.size(0)} is not size_n / 16 = {size_n // _LAYOUT_N}")
     _check(B.size(1) == size_k * _LAYOUT_N // _PACK,
            f"B.size(1) = {B.size(1)} is not packed size = {size_k * _LAYOUT_N // _PACK}")

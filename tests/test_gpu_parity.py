@@ -1260,6 +1260,16 @@ def test_native_class_table_rows_sampled(pk):
     assert ran == 9
 
 
+def sampled_rows(m: int):
+    """None (check every row) up to M = 1024; above: ~200 rows -- the first and last 32, the rows either side of every 256-row tile boundary near
+    the middle and the end (the tallest workgroup tile is 256 rows), and seeded others."""
+    if m <= 1024:
+        return None
+    edges = [r for b in (256, m // 2 // 256 * 256, (m - 1) // 256 * 256) for r in (b - 1, b, b + 1, b + 127, b + 128)]
+    rows = np.concatenate([np.arange(32), np.arange(m - 32, m), np.array(edges), np.random.default_rng(m).integers(0, m, 120)])
+    return np.unique(rows[(rows >= 0) & (rows < m)])
+
+
 def test_bench_cells_parity(pk):
     """Every cell bench.py times (tools/benchlib.py bench_cell_plan(): the SAME list) is run here through the same call --
     solution_id -1, or -2 / -3 for the native class -- at full size and checked: zero in -> zero out, one-hot rows read back
@@ -1272,8 +1282,13 @@ def test_bench_cells_parity(pk):
     assert {c["mode"] for c in full_plan if c["shape"].startswith("tp8")} == {"separate", "grouped"}            # -> test_grouped_launch
     plan = [c for c in full_plan if not c["mode"].startswith("hipblaslt") and c["shape"] in BL.LLAMA70B]
     assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx")}
-    assert {c["M"] for c in plan if (c["a"], c["w"], c["mode"]) == ("bf16", "mx", "auto")} == {1, 16, 512}   # the reference's only MX activation type
-    assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512}          # configs[1..2] + M = 512
+    mid, pre = set(BL.MID_MS), set(BL.PREFILL_MS)
+    assert mid == {32, 44, 64, 128} and pre == {1024, 2084, 4314, 16375}   # the reference's representative M list, tools/benchmarks/matmul.py:8-90
+    assert {c["M"] for c in plan if (c["a"], c["w"], c["mode"]) == ("bf16", "mx", "auto")} == {1, 16, 512} | mid | pre   # the reference's only MX activation type
+    assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512} | mid | pre              # configs[1..2] + M = 512 + mid M + prefill
+    assert {c["M"] for c in plan if c["mode"].startswith("native")} == {512} | pre
+    # the largest cell stays inside what one 32-bit buffer descriptor / grid can address (csrc/api.hip gemm_impl refuses beyond: test_layout_and_abi)
+    assert max(pre) * max(nk[0] for nk in BL.LLAMA70B.values()) * 2 < 1 << 32 and max(pre) * max(nk[1] for nk in BL.LLAMA70B.values()) < 1 << 32
     ran = 0
     for shape in BL.SHAPE_ORDER:
         n, k = BL.LLAMA70B[shape]
@@ -1285,20 +1300,27 @@ def test_bench_cells_parity(pk):
             for c in cells:
                 m, is_bf16, mode = c["M"], c["a"] == "bf16", c["mode"]
                 a = P.activations(m, is_bf16, 900 + m)
+                # prefill cells: the GEMM runs at its full M; the oracle checks a sample of its rows (first / last m-tiles of every tile height the
+                # kernels use, the ragged tail, seeded others) x the sampled columns -- the CPU side of a 16375-row check would take minutes per cell
+                rows = sampled_rows(m)
+                sel = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(t.device)] if isinstance(t, torch.Tensor) else t[rows])
                 tag = f"{shape} M={m} {c['a']}x{c['w']} {mode}"
                 if mode == "auto":
                     picked = pk.ops.resolve_solution(P.hints(is_bf16), m, n, k, -1)
                     assert picked and (picked >> 48) & 0xF not in (9, 13), tag
-                    P.check_properties(m, is_bf16)
-                    P.check_sampled(P.run(a, is_bf16), a, is_bf16, f"{tag} -> {picked:#x}")
+                    if m > 512:   # the arch table's open-ended bucket must not hand a prefill chunk a K split whose slabs outgrow the operands
+                        assert pk.ops.workspace_bytes(P.hints(is_bf16), m, n, k, -1) <= BL.alg_bytes(m, n, k, 16 if w == "nv" else 32), tag
+                    P.check_properties(min(m, 1024), is_bf16)
+                    P.check_sampled(sel(P.run(a, is_bf16)), sel(a), is_bf16, f"{tag} -> {picked:#x}")
                 else:
                     sid, code = {"native_mxfp8": (pk.SOLUTION_AUTO_NATIVE_MXFP8, 2), "native_mxfp6": (pk.SOLUTION_AUTO_NATIVE_MXFP6, 4),
                                  "native_mxfp4": (pk.SOLUTION_AUTO_NATIVE_MXFP4, 6)}[mode]
                     picked = pk.ops.resolve_solution(P.hints(is_bf16), m, n, k, sid)
                     assert picked and (picked >> 32) & 7 == code, tag
                     assert torch.count_nonzero(P.run(np.zeros_like(a), is_bf16, sid)) == 0, tag
-                    check_native_sampled(P, P.run(a, is_bf16, sid), a, code, f"{tag} -> {picked:#x}")
+                    check_native_sampled(P, sel(P.run(a, is_bf16, sid)), sel(a), code, f"{tag} -> {picked:#x}")
                 ran += 1
+                del a
             del P
             torch.cuda.empty_cache()
     assert ran == len(plan)
@@ -2104,6 +2126,52 @@ def test_quantized_silu_mul_output_feeds_the_next_gemm(pk, m, n, k, with_bias, f
         pk.ops.enable_native_fp4(False)
     with pytest.raises(RuntimeError):
         pk.mul_mxfp4_native(a, b, sp, gsd, m, n, k, sentinel, out_quantized=fmt)                             # no SiLU-mul
+
+
+@pytest.mark.parametrize("fmt", ["mxfp8", "mxfp6", "mxfp4"])
+def test_native_silu_mul_with_activation_only_scratch_writes_its_output(pk, fmt):
+    """AUTO_NATIVE_* + SiLU-mul on N = 1280, K = 8192, M = 512, where the native table names the 64 x 320 kernel (five n-tiles per
+    wave) with a K split of 4 / 8 -- fine while the reduce pass applies the activation.  With scratch that covers the quantised activations ONLY
+    (petit_native_workspace_bytes) the library used to drop the split, keep the kernel, and return PETIT_OK with C unwritten (that kernel's own
+    SiLU-mul epilogue exists for even n-tile counts only).  Now: the call re-picks a kernel that applies SiLU-mul itself; the output equals, within the
+    class tolerance, what the full-scratch call computes -- and a poison pattern in C is gone."""
+    import ctypes as C
+    from petit_kernel import _lib
+    m, n, k = 512, 1280, 8192
+    _, _, _, _, a, b, sp, gs = _mx_problem_on_device(pk, m, n, k, 77)
+    sid = NATIVE_SENTINEL(pk, fmt)
+    full = pk.mul_mxfp4_native(a, b, sp, gs, m, n, k, sid, activation="silu_mul")
+    torch.cuda.synchronize()
+    assert full.shape == (m, n // 2) and torch.isfinite(full.float()).all()
+    hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    epi = _lib.Epilogue(None, 1, 0)
+    need = int(_lib.lib.petit_native_workspace_bytes(m, k))
+    picked = int(_lib.lib.petit_gemm_resolve_solution(C.byref(hints), m, n, k, C.c_uint64(sid & (2 ** 64 - 1)), C.byref(epi), C.c_uint64(need)))
+    assert picked and picked >> 60 == 1 and ((picked >> 52) & 0xF) % 2 == 0, hex(picked)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    c = torch.full((m, n // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+    rc = _lib.lib.petit_gemm_mxfp4_native(C.c_void_p(c.data_ptr()), C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(sp.data_ptr()),
+                                          C.c_void_p(gs.data_ptr()), m, n, k, C.byref(hints), C.c_uint64(sid & (2 ** 64 - 1)), C.byref(epi), None,
+                                          C.c_void_p(ws.data_ptr()), C.c_uint64(need), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    assert torch.isfinite(c.float()).all(), "the output buffer was not (fully) written"
+    rms = full.float().pow(2).mean().sqrt().item()
+    rel = (c.float() - full.float()).pow(2).mean().sqrt().item() / rms
+    assert rel <= 2e-2, rel      # same quantised activations, same weights: only the summation order and one bf16 rounding differ
+    # an explicit id of the odd-n-tile kernel with SiLU-mul and no split is refused, never a silent no-op
+    pk.ops.enable_native_fp4(True)
+    try:
+        h = pk.PetitSolutionHints()
+        h.a_type = h.c_type = torch.bfloat16
+        h.b_type = pk.DataType.mxfloat4_e2m1
+        odd = [s_ for s_ in pk.ops.get_fp4_solutions(h, m, n, k) if (s_ >> 48) & 0xF in (9, 13) and ((s_ >> 52) & 0xF) % 2 == 1]
+        assert odd
+        for s_ in odd[:3]:
+            with pytest.raises(RuntimeError):
+                pk.mul_mxfp4_native(a, b, sp, gs, m, n, k, s_, activation="silu_mul")
+    finally:
+        pk.ops.enable_native_fp4(False)
 
 
 def test_mlp_block_accuracy_budget(pk):

@@ -280,6 +280,17 @@ def _default_solution_in_subprocess(env_extra, a_type, b_type, m, n, k):
     return int(out.strip().splitlines()[-1], 16)
 
 
+# The M a table row was measured at (tools/make_tuned_inc.py BUCKET): the upper end of its bucket, 2048 / 8192 for the two prefill buckets whose
+# upper end is not a measurement.  At THAT M solution_id = -1 resolves to exactly the row; elsewhere in the bucket to the same kernel, possibly with
+# a smaller K split (csrc/api.hip guarded_splitk).
+def row_rep_m(lo, hi):
+    return 8192 if hi == 1 << 20 else 2048 if (lo, hi) == (1025, 4096) else hi
+
+
+def same_kernel_split_at_most(got, row):
+    return (got ^ row) & ~(0xF << 60) == 0 and 1 <= (got >> 60) <= (row >> 60)
+
+
 def test_arch_table_rows_and_tune_file_override(tmp_path):
     """solution_id = -1 consults the measured table first (every row must name a kernel that exists and fits),
     and a $PETIT_AMD_TUNE_FILE row written in tools/tune.py's format takes precedence over it."""
@@ -291,8 +302,9 @@ def test_arch_table_rows_and_tune_file_override(tmp_path):
         at, bt, n, k, lo, hi, sol = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16)
         hints = _lib.SolutionHints(at, bt, at, 0)
         assert (sol >> 48) & 0xF not in (9, 13), "a native-FP4 kernel must never be a default"   # (as tools/make_tuned_inc.py)
+        assert _lib.lib.petit_gemm_default_solution(C.byref(hints), row_rep_m(lo, hi), n, k) == sol, (at, bt, n, k, lo, hi, hex(sol))
         for m in {lo, min(hi, lo + 3)}:
-            assert _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k) == sol, (at, bt, n, k, m, hex(sol))
+            assert same_kernel_split_at_most(_lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k), sol), (at, bt, n, k, m, hex(sol))
             assert "unknown" not in _lib.describe_solution(sol)
     # override: pick some other enumerated kernel for one of the table's shapes
     at, bt, n, k, lo, hi, sol = rows[0]
@@ -467,7 +479,7 @@ def test_builtin_tables_parse_and_name_kernels_of_this_build():
     assert len(shapes) >= 80
     for at, bt, n, k, lo, hi, sid in rows[::37]:                              # a sample through the ABI: the row is what AUTO resolves to
         h = _lib.SolutionHints(int(at), int(bt), int(at), 0)
-        assert _lib.lib.petit_gemm_default_solution(C.byref(h), int(lo), int(n), int(k)) == int(sid, 16)
+        assert _lib.lib.petit_gemm_default_solution(C.byref(h), row_rep_m(int(lo), int(hi)), int(n), int(k)) == int(sid, 16)
     cost = (ROOT / "petit-kernel_amd" / "csrc" / "cost_gfx950.inc").read_text()
     crow = re.findall(r"^\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), ([0-9.]+)f, ([0-9.]+)f, ([0-9.]+)f\},$", cost, re.M)
     assert len(crow) >= 40 and len(crow) == sum(1 for ln in cost.splitlines() if ln.startswith("{"))
@@ -585,7 +597,7 @@ def test_bench_line_stays_inside_the_drivers_record():
     for c in plan:
         dt = f"{c['a']}x{c['w']}" + ("" if c["mode"] == "auto" else f" {c['mode']}")
         cell = {"shape": c["shape"], "M": c["M"], "dt": dt, "us": 1234.56, "us_min": 1230.01, "frac": 0.6789, "sid": "1814411013100101", "kernel": "x" * 120}
-        cell["GBs" if c["M"] <= 16 else "TF"] = 4567 if c["M"] <= 16 else 1234.5
+        cell["GBs" if c["M"] <= BL.HBM_BOUND_MAX_M else "TF"] = 4567 if c["M"] <= BL.HBM_BOUND_MAX_M else 1234.5
         cells.append(cell)
     compact = bench.compact_cells(cells)
     line = {"metric": "bf16xnvfp4_gemm_achieved_hbm_bandwidth_m1_n8192_k8192", "value": 4690.994931410796, "unit": "GB/s", "n_gpus": 1, "steps": 20,
@@ -596,6 +608,7 @@ def test_bench_line_stays_inside_the_drivers_record():
     line.update(compact)
     text = json.dumps(line, separators=(",", ":"))
     assert len(text) <= 8192, len(text)
+    assert sum(len(r[2]) for r in compact["cells"]) >= len(plan) and all(len(r[2]) == len(r[3]) == len(compact["cells_m"][r[1]]) for r in compact["cells"])
     assert list(line)[-1] == "metric_cells" and len(compact["metric_cells"]) == 16
     assert {(r[0], r[1]) for r in compact["metric_cells"]} == {(s, m) for s in BL.SHAPE_ORDER for m in (1, 8, 16, 512)}
     assert all(len(r) == 6 for r in compact["metric_cells"] if r[1] <= 16)      # ... with the fraction of the 6.29 TB/s copy ceiling beside 8 TB/s
@@ -611,11 +624,12 @@ def test_native_class_default_picks():
                       (ROOT / "petit-kernel_amd/csrc/tuned_native_gfx950.inc").read_text())
     assert rows
     for at, bt, n, k, lo, hi, sol in rows:
-        at, bt, n, k, lo, sol = int(at), int(bt), int(n), int(k), int(lo), int(sol, 16)
+        at, bt, n, k, lo, hi, sol = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16)
         assert bt == _lib.CXX_DTYPE_MXFP4_E2M1 and (sol >> 48) & 0xF in (9, 13)
         h = _lib.SolutionHints(at, bt, at, 0)
         sentinel = {6: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 4: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, 2: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8}[(sol >> 32) & 7]
-        assert L.petit_gemm_resolve_solution(C.byref(h), lo, n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == sol
+        assert L.petit_gemm_resolve_solution(C.byref(h), row_rep_m(lo, hi), n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == sol
+        assert same_kernel_split_at_most(L.petit_gemm_resolve_solution(C.byref(h), lo, n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)), sol)
         assert "unknown" not in _lib.describe_solution(sol)
     for at in (_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP16):
         h = _lib.SolutionHints(at, _lib.CXX_DTYPE_MXFP4_E2M1, at, 0)
@@ -723,3 +737,101 @@ def test_new_entry_points_validate_before_they_launch():
     assert L.petit_gemm_tune(fake, fake, fake, 16, 512, 1024, C.byref(h_nv), C.byref(tp), None, C.c_uint64(0), None, C.byref(best), C.byref(us)) == _lib.PETIT_ERROR_BAD_ARGUMENT
     tp = _lib.TuneParams(C.sizeof(_lib.TuneParams), 3, 1, 0, None, None, 0, 0, 0.0, 0, 0, 0, 0)                              # unknown class
     assert L.petit_gemm_tune(fake, fake, fake, 16, 512, 1024, C.byref(h_nv), C.byref(tp), None, C.c_uint64(0), None, C.byref(best), C.byref(us)) == _lib.PETIT_ERROR_BAD_ARGUMENT
+
+
+# --- round 5: M buckets above 512, the K-split guard, the ranges the entry points accept ---------------------------------------------
+
+def _table_rows(name):
+    text = (ROOT / "petit-kernel_amd" / "csrc" / name).read_text()
+    return [(int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16))
+            for at, bt, n, k, lo, hi, sol in re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}", text)]
+
+
+def test_table_buckets_and_the_split_guard():
+    """the open-ended bucket [257, 1 << 20] is gone -- prefill has its own rows (513-1024, 1025-4096, 4097+) -- and no row of
+    either table names a cross-workgroup K split that the library's guard (csrc/api.hip guarded_splitk, restated in tools/split_buckets.py) would take
+    away at the M the row stands for: no split once the unsplit grid has >= 2 workgroups per CU, slabs never larger than the operands."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import split_buckets as SB
+    from petit_kernel import _lib
+    for name, native in (("tuned_gfx950.inc", False), ("tuned_native_gfx950.inc", True)):
+        rows = _table_rows(name)
+        per_shape = {}
+        for at, bt, n, k, lo, hi, sol in rows:
+            per_shape.setdefault((at, bt, n, k, (sol >> 32) & 7 if native else 0), []).append((lo, hi))
+            m = row_rep_m(lo, hi)
+            sk = (sol >> 60) & 0xF
+            assert SB.guarded_splitk(sol, m, n, k) == sk, (name, n, k, lo, hi, hex(sol))
+            if sk > 1:
+                bm, bn = SB.tile(sol)
+                assert -(-m // bm) * -(-n // bn) < 512
+                group = 16 if bt == _lib.CXX_DTYPE_FP4_E2M1 else 32
+                assert sk * m * n * 4 <= n * k // 2 + n * k // group + 2 * m * k + 2 * m * n
+        for key, ranges in per_shape.items():
+            ranges.sort()
+            assert (257, 1 << 20) not in ranges, key
+            if ranges[-1][1] == 1 << 20:   # (every shape of the generated tables reaches the last bucket)
+                assert ranges[-1][0] == 4097 and (1025, 4096) in ranges and (513, 1024) in ranges and (257, 512) in ranges, key
+    # a prefill chunk of the largest shape: whatever the row says, AUTO asks for no scratch beyond what the operands weigh -- and none at all here
+    h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    for (n, k) in [(57344, 8192), (8192, 28672), (10240, 8192), (8192, 8192), (1280, 8192)]:
+        for m in (1024, 2084, 4314, 16375):
+            assert _lib.lib.petit_gemm_workspace_bytes(C.byref(h), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO)) <= n * k // 2 + n * k // 16 + 2 * m * (n + k), (m, n, k)
+        assert _lib.lib.petit_gemm_workspace_bytes(C.byref(h), 16375, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO)) == 0, (n, k)
+    # and a run-time row measured at a small M is guarded the same way when a larger M of its range is asked for
+    code = r"""
+import sys, ctypes as C
+sys.path.insert(0, %r)
+from petit_kernel import _lib
+L = _lib.lib
+h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+cnt = C.c_uint(0)
+L.petit_gemm_get_solutions(C.byref(h), 300, 4352, 8192, None, C.byref(cnt))
+ids = (C.c_uint64 * cnt.value)()
+L.petit_gemm_get_solutions(C.byref(h), 300, 4352, 8192, ids, C.byref(cnt))
+tiled = next(i for i in ids if (i >> 48) & 0xF == 8 and (i & 0xFF) == 4)       # a 64-row tiled kernel
+row = (tiled & ~(0xF << 60)) | (2 << 60)
+assert L.petit_tune_insert(C.byref(h), 4352, 8192, 257, 1 << 20, C.c_uint64(row)) == 0
+print(hex(L.petit_gemm_default_solution(C.byref(h), 300, 4352, 8192)), hex(L.petit_gemm_default_solution(C.byref(h), 16375, 4352, 8192)), hex(row))
+""" % str(ROOT / "petit-kernel_amd")
+    import subprocess
+    small, large, row = (int(x, 16) for x in subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split())
+    assert small == row and large == (row & ~(0xF << 60)) | (1 << 60)
+
+
+def test_problem_ranges_are_refused_not_wrapped():
+    """M beyond the tables' last bucket, and a native-class problem whose quantised activations outgrow one 32-bit buffer descriptor, return
+    PETIT_ERROR_PROBLEM_SHAPE before anything is launched (no GPU here: a launch would fail differently)."""
+    from petit_kernel import _lib
+    L = _lib.lib
+    buf = (C.c_uint * 64)()
+    p = C.cast(buf, C.c_void_p)
+    h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    assert L.petit_gemm_fp4_fp16_grid(p, p, p, p, p, (1 << 20) + 1, 8192, 8192, C.byref(h), C.c_uint64(_lib.PETIT_SOLUTION_AUTO), None) == 1
+    hm = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    ws = C.c_void_p(256)
+    for sentinel in (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4):
+        assert L.petit_gemm_mxfp4_native(p, p, p, p, p, 65535, 8192, 66560, C.byref(hm), C.c_uint64(sentinel), None, None, ws, C.c_uint64(1 << 40), None) == 1
+        assert L.petit_gemm_mxfp4_native(p, p, p, p, p, 65536, 8192, 8192, C.byref(hm), C.c_uint64(sentinel), None, None, ws, C.c_uint64(1 << 40), None) == 1
+
+
+def test_native_silu_mul_without_slab_scratch_names_a_kernel_that_applies_it():
+    """the native table has rows like the 64 x 320 kernel (five n-tiles per wave) x K split 4 for N = 1280, K = 8192, M >= 257.
+    With SiLU-mul such a row is fine while the split's reduce pass applies the activation -- but when the caller's scratch covers the quantised
+    activations only, the unsplit fallback must not keep a kernel whose own epilogue cannot (odd n-tiles per wave): the resolved kernel has an even
+    count, whatever the scratch."""
+    from petit_kernel import _lib
+    L = _lib.lib
+    epi = _lib.Epilogue(None, 1, 0)
+    for at in (_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP16):
+        h = _lib.SolutionHints(at, _lib.CXX_DTYPE_MXFP4_E2M1, at, 0)
+        for sentinel in (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4):
+            for (m, n, k) in [(512, 1280, 8192), (300, 1280, 8192), (512, 2560, 8192), (1024, 1280, 8192), (512, 7168, 2048)]:
+                for ws in (1 << 40, L.petit_native_workspace_bytes(m, k)):
+                    sid = L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), C.byref(epi), C.c_uint64(ws))
+                    assert sid, (m, n, k, ws)
+                    ntw, split = (sid >> 52) & 0xF, sid >> 60
+                    assert split > 1 or ntw % 2 == 0, (m, n, k, ws, hex(sid), _lib.describe_solution(sid))
+                    if ws < 1 << 40:
+                        assert split == 1 and ntw % 2 == 0, (hex(sid), _lib.describe_solution(sid))

@@ -5,15 +5,33 @@ import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 d20 = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]) if len(sys.argv) > 2 else None
-def as_dict(c):   # round 4: the line carries compact rows [shape, M, "dtypes mode", us, rate, frac]
-    if isinstance(c, dict):
-        return c
-    out = {"shape": c[0], "M": c[1], "dt": c[2], "us": c[3], "frac": c[5]}
-    out["GBs" if (c[1] <= 16 and c[0] != "mlp") else "TF"] = c[4]
+PEAK = {"hipblaslt_fp8": 5000.0, "native_mxfp8": 5000.0, "native_mxfp6": 10000.0, "native_mxfp4": 10000.0, "mlp_native_mxfp8_pipeline": 5000.0}
+
+
+def expand(d):
+    """round 5: the line carries one row per (shape, dtypes mode): [shape, dt, [us per M], [rate per M]] over d["cells_m"][dt];
+    round 4: [shape, M, dt, us, rate, frac]; earlier / the side file: dicts."""
+    out = []
+    for c in d["cells"]:
+        if isinstance(c, dict):
+            out.append(c)
+        elif "cells_m" in d:
+            shape, dt, us, rates = c
+            for m, u, r in zip(d["cells_m"][dt], us, rates):
+                if u is None:
+                    continue
+                hbm = m <= 64 and shape != "mlp"
+                mode = dt.split()[-1] if " " in dt else ""
+                peak = 8000.0 if hbm else PEAK.get(mode, 10000.0 if mode.startswith("mlp_native") else 2500.0)
+                out.append({"shape": shape, "M": m, "dt": dt, "us": u, "frac": r / peak, "GBs" if hbm else "TF": r})
+        else:
+            cell = {"shape": c[0], "M": c[1], "dt": c[2], "us": c[3], "frac": c[5]}
+            cell["GBs" if (c[1] <= 16 and c[0] != "mlp") else "TF"] = c[4]
+            out.append(cell)
     return out
 
 
-cells = {(c["shape"], c["M"], c["dt"]): c for c in map(as_dict, d["cells"])}
+cells = {(c["shape"], c["M"], c["dt"]): c for c in expand(d)}
 COPY_CEILING = 6290.0   # GB/s: the guide's measured HBM copy ceiling (what a pure stream reaches of the 8 TB/s spec)
 shapes = ["qkv", "o", "gate_up", "down"]
 print(f"Headline (BASELINE configs[1], M = 1, N = K = 8192, bf16 x NVFP4, solution_id = -1): **{d['ms_per_step'] * 1e3:.2f} us/step = {d['value']:.0f} GB/s = "
@@ -34,6 +52,25 @@ print("|---|" + "---|" * len(cols))
 for s in shapes:
     print(f"| {s} | " + " | ".join(f"{cells[(s, 512, dt)]['us']:.1f} us, {cells[(s, 512, dt)]['TF']:.0f} TF, {cells[(s, 512, dt)]['frac']:.2f}" if (s, 512, dt) in cells else "-"
                                    for dt, _ in cols) + " |")
+if any(k[1] == 32 for k in cells):
+    print("\nMid M (17 <= M <= 128; bf16 activations; M <= 64: us, fraction of 8 TB/s / of the copy ceiling; M = 128: us, TFLOP/s):\n")
+    cols = [(dt, m) for dt in ("bf16xnv", "bf16xmx") for m in (32, 44, 64, 128)]
+    print("| shape | " + " | ".join(f"{dt} M={m}" for dt, m in cols) + " |")
+    print("|---|" + "---|" * len(cols))
+    for s in shapes:
+        def fmt(c):
+            return f"{c['us']:.2f} us, {c['frac']:.2f} / {c['GBs'] / COPY_CEILING:.2f}" if "GBs" in c else f"{c['us']:.1f} us, {c['TF']:.0f} TF"
+        print(f"| {s} | " + " | ".join(fmt(cells[(s, m, dt)]) if (s, m, dt) in cells else "-" for dt, m in cols) + " |")
+pre = sorted({k[1] for k in cells if k[1] > 512})
+if pre:
+    print("\nPrefill (M > 512; TFLOP/s, native cells include the activation-quantiser launch):\n")
+    cols = [("bf16xnv", "bf16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("bf16xmx native_mxfp8", "native MXFP8"), ("bf16xmx native_mxfp6", "native MXFP6"),
+            ("bf16xmx native_mxfp4", "native MXFP4"), ("bf16xdense hipblaslt", "hipBLASLt bf16"), ("fp8xdense hipblaslt_fp8", "hipBLASLt FP8")]
+    print("| shape | M | " + " | ".join(name for _, name in cols) + " |")
+    print("|---|---|" + "---|" * len(cols))
+    for s in shapes:
+        for m in pre:
+            print(f"| {s} | {m} | " + " | ".join(f"{cells[(s, m, dt)]['us']:.0f} us, {cells[(s, m, dt)]['TF']:.0f} TF" if (s, m, dt) in cells else "-" for dt, _ in cols) + " |")
 if any(k[1] == 256 for k in cells):
     print("\nfp16 x NVFP4 at M = 256 (the reference benchmark's middle column): " +
           ", ".join(f"{s} {cells[(s, 256, 'fp16xnv')]['us']:.1f} us = {cells[(s, 256, 'fp16xnv')]['TF']:.0f} TFLOP/s" for s in shapes if (s, 256, "fp16xnv") in cells) + ".")

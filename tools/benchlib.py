@@ -42,6 +42,11 @@ LLAMA70B = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "
 SHAPE_ORDER = ("qkv", "o", "gate_up", "down")
 
 
+MID_MS = (32, 44, 64, 128)                  # batched decode: between the decode kernels and the large-M tiles (tools/benchmarks/matmul.py:8-90 lists 15, 44, ...)
+PREFILL_MS = (1024, 2084, 4314, 16375)       # prefill chunks; the last three are entries of the reference's own list (ragged on purpose)
+HBM_BOUND_MAX_M = 64                         # cells up to this M are reported as GB/s against the HBM roofline (intensity at M = 64: 228 FLOP/B, ridge 315), above as TFLOP/s
+
+
 def bench_cell_plan() -> list:
     plan = []
     # the bandwidth-bound cells of every shape first (a decode cell timed right after seconds of 1.3 kW compute reads 5-10 % slow)
@@ -50,6 +55,9 @@ def bench_cell_plan() -> list:
         plan += [dict(shape=shape, M=16, a="fp16", w="nv", mode="auto")]
         plan += [dict(shape=shape, M=m, a="fp16", w="mx", mode="auto") for m in (1, 16)]     # BASELINE configs[3]; plain MXFP4 hints (the kernels test the scale range)
         plan += [dict(shape=shape, M=m, a="bf16", w="mx", mode="auto") for m in (1, 16)]     # the reference's only MX activation type (gemm_fp4_fp16_grid.cc:55-64)
+    # mid M (round 5): the everyday batch sizes of a serving engine, 17 <= M <= 128
+    for shape in SHAPE_ORDER:
+        plan += [dict(shape=shape, M=m, a="bf16", w=w, mode="auto") for w in ("nv", "mx") for m in MID_MS]
     for shape in SHAPE_ORDER:
         # (M = 256 in the reference benchmark's default dtype: the middle column of its ENTRIES, tools/benchmarks/matmul.py:92-117)
         plan += [dict(shape=shape, M=256, a="fp16", w="nv", mode="auto"),
@@ -58,6 +66,13 @@ def bench_cell_plan() -> list:
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp6"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
                  dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=512, a="fp8", w="dense", mode="hipblaslt_fp8")]
+    # prefill (round 5): M > 512 up to the reference list's largest entries, exact NV / MX, the three native classes, the vendor's bf16 and FP8 GEMMs
+    for shape in SHAPE_ORDER:
+        for m in PREFILL_MS:
+            plan += [dict(shape=shape, M=m, a="bf16", w="nv", mode="auto"), dict(shape=shape, M=m, a="bf16", w="mx", mode="auto"),
+                     dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp6"),
+                     dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp4"),
+                     dict(shape=shape, M=m, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=m, a="fp8", w="dense", mode="hipblaslt_fp8")]
     # launch-gap-bound shapes: the q / k / v shards of a TP-8 deployment (1280 x 8192 each) as three launches and as one grouped launch
     plan += [dict(shape="tp8_qkv_3x1280", M=m, a="bf16", w="nv", mode=mode) for m in (1, 16) for mode in ("separate", "grouped")]
     # the gated-MLP block (gate_up -> SiLU-mul -> down) as a unit: what the quantising epilogue buys the native class
