@@ -299,7 +299,7 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
         unsigned launches = rq.launches;
         std::vector<float> us;
         for (unsigned sm = 0; sm <= samples; ++sm) {
-            const unsigned batch = launches ? launches : 4;
+            const unsigned batch = launches ? launches : (sm == 0 ? 2 : 4); // (the untimed sample only sizes the batch)
             (void)hipEventRecord(e0, stream);
             for (unsigned l = 0; l < batch; ++l)
                 if (run(id, rq.c, rot++) != kOk)
@@ -313,8 +313,8 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
             if (rc != kOk)
                 break;
             if (sm == 0) { // untimed: choose the batch so that a sample lasts ~0.3 ms (at least 4, at most 256 launches)
-                if (!launches)
-                    launches = (unsigned)std::min(256.0f, std::max(4.0f, 300.0f / std::max(per, 0.5f)));
+                if (!launches) // (2 launches per sample are enough once a launch takes a millisecond: prefill problems)
+                    launches = (unsigned)std::min(256.0f, std::max(per >= 1000.0f ? 2.0f : 4.0f, 300.0f / std::max(per, 0.5f)));
                 continue;
             }
             us.push_back(per);

@@ -69,15 +69,20 @@ def main():
     ap.add_argument("--budget-s", type=float, default=1e9)
     ap.add_argument("--klass", default="exact", choices=["exact", "native_mxfp8", "native_mxfp6", "native_mxfp4"],
                     help="the native classes (MXFP4 weights only: --families mx:bf16,mx:f16) fill csrc/tuned_native_gfx950.inc: tools/make_tuned_inc.py --native <out>.tune.txt")
+    ap.add_argument("--only", default="", help="comma-separated substrings: keep the shapes whose description (model, layer, TP) contains one, e.g. llama3-70b,r01-r03")
+    ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--list", action="store_true", help="print the shape list and exit (no GPU needed)")
     args = ap.parse_args()
     shapes = model_shapes()
     table = sorted(nk for nk in shapes if nk not in HELDOUT)
     held = sorted(HELDOUT)
     todo = table if args.part == "table" else held if args.part == "heldout" else table + held
+    if args.only:
+        keys = [x for x in args.only.split(",") if x]
+        todo = [nk for nk in todo if any(x in shapes.get(nk, "held-out") for x in keys)]
     if args.list:
-        for nk in table:
-            print(f"{nk[0]}x{nk[1]}  {shapes[nk]}")
+        for nk in todo:
+            print(f"{nk[0]}x{nk[1]}  {shapes.get(nk, 'held-out')}")
         print(f"{len(table)} table shapes, {len(held)} held-out shapes, x {len(args.ms.split(','))} M x {len(args.families.split(','))} families")
         return
     out_dir = Path(args.out_dir)
@@ -101,7 +106,7 @@ def main():
             for m in ms:
                 g = BL.Gemm(w, m, dtype, dev)
                 try:
-                    sid, us = pk.tune_tensors(g.a, w.packed, g.gs, m, n, k, {"nv": "nvfp4", "mx": "mxfp4"}[fmt], klass=args.klass, persist=False, samples=5)
+                    sid, us = pk.tune_tensors(g.a, w.packed, g.gs, m, n, k, {"nv": "nvfp4", "mx": "mxfp4"}[fmt], klass=args.klass, persist=False, samples=args.samples)
                 except RuntimeError as exc:
                     print(f"{fam} {n}x{k} M={m}: {exc}", flush=True)
                     continue
