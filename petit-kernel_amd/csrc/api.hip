@@ -46,9 +46,9 @@ static const SolutionEntry *concat_parts(std::vector<SolutionEntry> &store, std:
         *count = (int)store.size();                                                                           \
         return table;                                                                                         \
     }
-PETIT_FAMILY_TABLE(nv_bf16, solutions_nv_bf16_p1, solutions_nv_bf16_p2, solutions_nv_bf16_p3, solutions_nv_bf16_p4)
-PETIT_FAMILY_TABLE(nv_f16, solutions_nv_f16_p1, solutions_nv_f16_p2, solutions_nv_f16_p3, solutions_nv_f16_p4)
-PETIT_FAMILY_TABLE(mx_bf16, solutions_mx_bf16_p1, solutions_mx_bf16_p2, solutions_mx_bf16_p3, solutions_mx_bf16_p4, solutions_mx_bf16_p5)
+PETIT_FAMILY_TABLE(nv_bf16, solutions_nv_bf16_p1, solutions_nv_bf16_p2, solutions_nv_bf16_p3, solutions_nv_bf16_p4, solutions_nv_bf16_p6)
+PETIT_FAMILY_TABLE(nv_f16, solutions_nv_f16_p1, solutions_nv_f16_p2, solutions_nv_f16_p3, solutions_nv_f16_p4, solutions_nv_f16_p6)
+PETIT_FAMILY_TABLE(mx_bf16, solutions_mx_bf16_p1, solutions_mx_bf16_p2, solutions_mx_bf16_p3, solutions_mx_bf16_p4, solutions_mx_bf16_p5, solutions_mx_bf16_p6)
 PETIT_FAMILY_TABLE(mx_f16, solutions_mx_f16_p1, solutions_mx_f16_p2, solutions_mx_f16_p3, solutions_mx_f16_p4, solutions_mx_f16_p5)
 #undef PETIT_FAMILY_TABLE
 
@@ -150,6 +150,7 @@ void *registered_workspace(int dev, void *stream, uint64_t need, bool *busy) {
 // a 256-CU part idle on 4096^2 -- SURVEY.md Appendix C.)
 // SiLU-mul epilogue: a wave must hold the gate and the up tile of an output tile -> even n-tiles per wave
 bool is_shared(const SolutionEntry &e) { return e.shape.am == kWideAm && e.shape.wm == 5; } // gemm_shared.hpp (plain / bias epilogue only)
+bool is_batch(const SolutionEntry &e) { return e.shape.am == 0 && e.shape.wm == 2; }      // gemm_batch.hpp (17 <= M <= 128; reaches the default path through the arch table)
 enum : unsigned { kNeedK32 = 1u, kNeedQuantOut = 2u }; // restrictions of the native pipeline (entry_allows)
 bool act_ok(const SolutionEntry &e) { return e.shape.nt % 2 == 0 && !is_shared(e); }
 // SiLU-mul with this (kernel, K split): unsplit, the kernel's own epilogue does it (gate and up tile in one wave: act_ok); with a cross-workgroup
@@ -298,7 +299,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
                 }
                 us -= 0.001 * s.d; // deeper ring on a tie
             } else {
-                if (s.am != 0 || s.wn != 1)
+                if (s.am != 0 || s.wn != 1 || s.wm != 1)
                     continue;
                 us = stream_cost_us(e, m, n, k, arch.num_cus);
                 // the swept winners: WK = 4, fragments requested 2 tiles ahead
@@ -378,7 +379,7 @@ const SolutionEntry *heuristic(const Family &fam, unsigned m, unsigned n, unsign
     }
     if (!best) { // relax the m-tile preference
         for (int i = 0; i < fam.count; ++i)
-            if (entry_fits(fam.entries[i], m, k) && (!need_grouped || fam.entries[i].launch_grouped) && fam.entries[i].shape.am != kTiledAm &&
+            if (entry_fits(fam.entries[i], m, k) && (!need_grouped || fam.entries[i].launch_grouped) && fam.entries[i].shape.am != kTiledAm && !is_batch(fam.entries[i]) &&
                 !is_native_am(fam.entries[i].shape.am) && fam.entries[i].shape.am != kWideAm && (!need_pairs || act_ok(fam.entries[i])) &&
                 (!best || fam.entries[i].shape.mt > best->shape.mt))
                 best = &fam.entries[i];
@@ -695,7 +696,9 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         // kernels none
         // (measured: down 8192 x 28672 at M = 16, staged 16 x 64 tiles with a K split of 2: 29.0 us against 30.5 unsplit -- every CU
         // then pulls half of the activations)
-        const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1);
+        const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1) || is_batch(e);
+        if (is_batch(e) && m > 256)
+            continue; // (32-128-row workgroups that each stream their whole column block: never a candidate for prefill)
         if (!splittable)
             continue;
         for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)
@@ -1302,6 +1305,12 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         snprintf(buf, len, "tiled %sx%s ks%d mt%d ntw%d waves%d d%d splitk%u  (wg tile %dx%d, %d threads)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
                  s.mt, s.nt, s.wn, s.d, solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn);
+        return kOk;
+    }
+    if (s.am == 0 && s.wm == 2) {
+        snprintf(buf, len, "batch %sx%s ks%d mt%d nt%d wn%d wk%d d%d splitk%u  (wg tile %dx%d, %d threads: %d K parts reduced in LDS, activation tiles shared by %d waves)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks, s.mt, s.nt, s.wn, s.wk, s.d,
+                 solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * s.wk, s.wk, s.wn);
         return kOk;
     }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",

@@ -1,0 +1,293 @@
+// gemm_batch.hpp -- weight streaming for 17 <= M <= 128 ("batched decode": the everyday batch sizes of a serving engine).
+//
+// The regime between the decode kernels (M <= 16: one m-tile, HBM-bound) and the large-M tiles (M >= 128: MFMA-bound).  The weights
+// are still the dominant HBM stream -- at M = 64 on 8192 x 8192 the arithmetic intensity is 228 FLOP/B against a ridge of 315 -- but
+// two more budgets bind before HBM does (profiles/r05_midm_pmc.md):
+//   * what a CU must pull in: its share of W plus EVERY activation row of its K range, once per workgroup: a workgroup that walks
+//     the whole K at M = 64 ingests 1 MiB of activations for 128 KiB of weights through a ~64 B/clk vector-memory path;
+//   * the second launch of a cross-workgroup K split: splitk * M * N * 4 bytes of fp32 slabs written and read back -- at M = 64,
+//     split 8, half as many bytes as the weights themselves (the tiled kernels' answer to the first budget: 13 us GEMM + 5 us reduce).
+// This kernel is gemm_mid.hpp's organisation (5 <= M <= 16) carried to MT m-tiles: a workgroup is WN x WK waves; K is split over the
+// WK parts INSIDE the workgroup (partial sums meet once, in LDS, after the loop: no slabs), the WN waves of a part share one
+// activation tile per k-tile in LDS (BM = 16 MT rows x 256 B, global -> LDS by buffer_load ... lds, D tiles ahead in a ring of D + 1
+// slots, counted vmcnt + bare s_barrier per step), W never touches LDS (ring of D tiles in VGPRs per n-tile), every unpacked weight
+// word feeds MT MFMAs.  8-16 waves per CU walk disjoint K ranges and column blocks, so unpack VALU, MFMA and the LDS fragment reads of
+// different waves overlap without any intra-wave software pipelining.  An optional split across workgroups (gridDim.z, fp32 slabs +
+// the fixed-order reduce pass) remains for shapes whose N alone cannot fill the chip.
+// Reference counterpart: fp4/algo_chooser.cc:89-104 (its `m <= 64` branch: the same 16x32 / 32x32 tiles as decode, K walked by four
+// warps, W through LDS) is the reference's whole answer to this regime.
+#pragma once
+
+#include "device_common.hpp"
+
+namespace petit_amd {
+
+//   AT    Bf16 / Fp16 activations (and output)
+//   FMT   kFmtNv / kFmtMx
+//   KS    tiles per span
+//   MT    m-tiles (of 16 rows) per workgroup: BM = 16 MT
+//   NT    n-tiles per wave
+//   WN,WK waves along N / K in the workgroup (the WN waves of a K part share its activation tiles)
+//   D     ring depth in k-tiles (W in VGPRs, A in LDS slots), divides KS
+template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_> struct BatchCfg {
+    using AT = AT_;
+    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_;
+    static constexpr int kThreads = 64 * WN * WK;
+    static constexpr int BM = 16 * MT;
+    static constexpr int kTileU4 = BM * 16;               // one activation tile: BM rows x 16 units of 16 B
+    static constexpr int kSlots = D + 1;
+    static constexpr int kPartU4 = kSlots * kTileU4;      // per K part
+    static constexpr int kDma = BM * 16 / 64 / WN;        // KiB wave-loads per wave per tile
+    static constexpr int kRedU4 = WN * NT * MT * 64;      // float4 partial outputs per K part
+    // the reduction scratch reuses the activation ring (every wave has left the loop before the first partial sum is parked)
+    static constexpr int kSmemU4 = WK * kPartU4 > WK * kRedU4 ? WK * kPartU4 : WK * kRedU4;
+    static_assert(MT >= 2 && MT <= 8, "2..8 m-tiles: 32..128 rows");
+    static_assert(kDma >= 1 && kDma * WN * 4 == BM, "the waves of a K part split a tile into whole KiB loads");
+    static_assert(KS % D == 0, "ring depth must divide the span");
+    static_assert(!AT::kBfp && !AT::kAdaptive, "plain bf16 / fp16 activations");
+    static_assert(kThreads <= 1024 && kSmemU4 * 16 <= 160 * 1024, "workgroup / LDS budget");
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *arg_w, const void *arg_s, const void *arg_a, unsigned arg_k,
+                                                                   unsigned arg_n, unsigned arg_m, unsigned arg_spw, unsigned arg_act,
+                                                                   void *arg_c, const float *arg_gs, const void *arg_bias,
+                                                                   float *arg_workspace) {
+    using AT = typename Cfg::AT;
+    using Frag = typename AT::frag;
+    constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT, WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D;
+    constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
+    constexpr unsigned kOob = 0x80000000u;
+    // loads a wave issues per step: its slice of the A tile + one W tile per n-tile
+    constexpr int kLoadsPerStep = Cfg::kDma + NT;
+
+    __shared__ u32x4 smem[Cfg::kSmemU4];
+
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned wn = wave % WN, wk = wave / WN;
+    const unsigned r = lane & 15u, g = lane >> 4;
+
+    const unsigned ktiles = arg_k / kTileK;
+    const unsigned nspans = ktiles / KS;
+    const unsigned ntiles = arg_n / kTileN;
+    const unsigned nt0 = (blockIdx.x * WN + wn) * NT;
+    const unsigned m0 = blockIdx.y * Cfg::BM;
+    // K range of this part: gridDim.z splits K across workgroups first, WK across the parts of a workgroup second.  Every wave walks arg_spw
+    // spans' worth of barriers (the count must agree across the workgroup); a part whose range ends early idles through the rest.
+    const unsigned part = blockIdx.z * WK + wk;
+    const unsigned sp_begin = min(part * arg_spw, nspans);
+    const unsigned sp_end = min(sp_begin + arg_spw, nspans);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 *const a_part = smem + wk * Cfg::kPartU4;
+    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)NT, ntiles - nt0) : 0u;
+    const unsigned w_row_bytes = ktiles * kTileBytes;
+    const unsigned s_row_bytes = (FMT == kFmtNv) ? arg_k : arg_k / 2;
+    const unsigned rows = min(arg_m - m0, (unsigned)Cfg::BM);
+    const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, arg_act) : 0u;
+    const unsigned span_tiles = !valid_nt ? 0u : arg_act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc((const char *)arg_w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
+    const __amdgpu_buffer_rsrc_t s_rsrc = make_rsrc((const char *)arg_s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc((const char *)arg_a + (size_t)m0 * arg_k * 2, rows * arg_k * 2);
+
+    unsigned w_voff[NT], s_voff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const unsigned rel = valid_nt ? physical_tile(nt0 + nt, ntiles, arg_act) - pt0 : 0u;
+        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
+        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
+    }
+    // A tile slice of this wave: wave-load i covers rows 4 (i WN + wn) .. + 3; lane l -> row + l / 16, position l % 16, which receives
+    // unit (l % 16) ^ (row % 16) of that row.  Rows >= M fall out of the descriptor: zeros.
+    unsigned dma_voff[Cfg::kDma];
+#pragma unroll
+    for (int i = 0; i < Cfg::kDma; ++i) {
+        const unsigned row = 4 * (i * WN + wn) + (lane >> 4);
+        dma_voff[i] = row * arg_k * 2 + (((lane & 15u) ^ (row & 15u)) * 16);
+    }
+    auto dma_a_tile = [&](unsigned slot, unsigned kt) {
+#pragma unroll
+        for (int i = 0; i < Cfg::kDma; ++i) {
+#if defined(__HIP_DEVICE_COMPILE__) // (the host pass knows neither the builtin nor the LDS address space)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                a_rsrc, (__attribute__((address_space(3))) void *)(a_part + slot * Cfg::kTileU4 + (i * WN + wn) * 64), 16, dma_voff[i],
+                kt * 256, 0, 0);
+#else
+            (void)slot, (void)kt;
+#endif
+        }
+    };
+    // fragment of (m-tile mt, MFMA j): row 16 mt + r, unit (4 g + j) ^ r
+    const u32x4 *fptr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        fptr[j] = a_part + (int)(r * 16 + ((g * 4 + j) ^ r));
+
+    const bool part_on = sp_begin < sp_end;
+    if (part_on) {
+        const unsigned kt_begin = sp_begin * KS;
+        // --- prologue: D steps of loads, oldest first (A slice, then W, per step)
+        ScaleRec<FMT, KS> srec[NT], srec_next[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], sp_begin * 64 * kRecBytes);
+        u32x4 wring[D][NT];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            const unsigned kt = kt_begin + i; // (a part owns at least one span and D <= KS)
+            dma_a_tile(kt % Cfg::kSlots, kt);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], kt * kTileBytes, kAuxNt);
+        }
+        // tile kt_begin visible to the whole part: D - 1 steps of loads may stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * kLoadsPerStep) : "memory");
+        __builtin_amdgcn_s_barrier();
+
+        unsigned aslot = kt_begin % Cfg::kSlots; // LDS slot of the step's tile, advanced once per step
+        auto span_body = [&](const unsigned sp, auto last_c) {
+            constexpr bool kLast = decltype(last_c)::value;
+            const unsigned kt0 = sp * KS;
+            if constexpr (!kLast) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    srec_next[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], (sp + 1) * 64 * kRecBytes);
+            }
+            static_for<0, KS>([&](auto t_c) {
+                constexpr int T = decltype(t_c)::value;
+                constexpr int SLOT = T % D;
+                const unsigned kt = kt0 + T;
+                const unsigned cur = aslot * Cfg::kTileU4; // (tile kt became visible at the barrier that ended the previous step)
+                // loads of step kt + D (it exists unless this is the wave's last span and T + D runs past it)
+                constexpr bool kAhead = !kLast || (T + D < KS);
+                const unsigned ktn = kt + D;
+                if constexpr (kAhead)
+                    dma_a_tile(aslot == 0 ? (unsigned)D : aslot - 1, ktn); // (aslot + D) % (D + 1)
+                aslot = aslot + 1 == (unsigned)Cfg::kSlots ? 0u : aslot + 1;
+                // (hipcc otherwise hoists the pure unpack VALU of several steps of the unrolled span to the top: 256 VGPRs and spills)
+                __builtin_amdgcn_sched_barrier(0);
+                // this step's weight words, unpacked once, used by all MT m-tiles
+                Frag wf[NT][4];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float s_lo, s_hi;
+                    tile_scales<FMT, KS, T>(srec[nt], s_lo, s_hi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned w = wring[SLOT][nt][j];
+                        if constexpr (FMT == kFmtNv)
+                            wf[nt][j] = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
+                        else
+                            wf[nt][j] = unpack_mx(AT{}, w, s_lo);
+                    }
+                }
+                if constexpr (kAhead) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], ktn * kTileBytes, kAuxNt);
+                }
+                // word j of every m-tile before word j + 1: MT * NT independent accumulators between two MFMAs on the same one
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    Frag af[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        af[mt] = __builtin_bit_cast(Frag, fptr[j][cur + mt * 256]);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = mfma16(wf[nt][j], af[mt], acc[mt][nt]);
+                }
+                // tile kt + 1 complete (this wave's slice), then visible (everybody's): the steps after it that have been
+                // requested (D - 1 of them, fewer at the end of the wave's range) stay in flight
+                constexpr int kYounger = !kLast ? D - 1 : (KS - 2 - T < 0 ? 0 : (KS - 2 - T < D - 1 ? KS - 2 - T : D - 1));
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kYounger * kLoadsPerStep) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (!kLast) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    srec[nt] = srec_next[nt];
+            }
+        };
+        for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+            span_body(sp, std::false_type{});
+        span_body(sp_end - 1, std::true_type{});
+    }
+    // barrier count of the spans this part does not have (ragged K split): 1 for the prologue + KS per span
+    {
+        const unsigned mine = part_on ? 1u + (sp_end - sp_begin) * KS : 0u;
+        const unsigned want = 1u + arg_spw * KS;
+        for (unsigned i = mine; i < want; ++i)
+            __builtin_amdgcn_s_barrier();
+    }
+
+    // --- cross-wave K reduction through LDS (the activation ring's memory: every wave is past its last fragment read), then the epilogue
+    f32x4 *const red = reinterpret_cast<f32x4 *>(smem);
+    constexpr int kItems = Cfg::kRedU4; // per K part: [(wn NT + nt) MT + mt][lane]
+    if constexpr (WK > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                red[wk * kItems + ((wn * NT + nt) * MT + mt) * 64 + lane] = acc[mt][nt];
+        __syncthreads();
+    }
+    const float gs = *arg_gs;
+    // every thread finishes a share of the workgroup's (tile, lane) items: with WK parts each wave takes 1 / WK of ITS OWN tiles' items
+    // (the other parts' copies of the same item come from LDS), so the stores stay 8 bytes per lane, 16 rows x 32 B per instruction
+    constexpr int kPerWave = NT * MT; // accumulator tiles per wave
+#pragma unroll
+    for (int t = 0; t < kPerWave; ++t) {
+        if (WK > 1 && (unsigned)(t % WK) != wk)
+            continue;
+        const int nt = t / MT, mt = t % MT; // (compile-time after unrolling)
+        if (arg_act && nt % 2 != 0)
+            continue; // the up half is consumed together with its gate tile
+        const unsigned item = ((wn * NT + nt) * MT + mt) * 64 + lane;
+        f32x4 v;
+        if constexpr (WK > 1) {
+            v = red[item];
+#pragma unroll
+            for (int q = 1; q < WK; ++q)
+                v += red[q * kItems + item];
+        } else {
+            v = acc[mt][nt];
+        }
+        const unsigned m = m0 + mt * 16 + r;
+        const unsigned ntile = nt0 + nt;
+        if (m >= arg_m || (unsigned)nt >= valid_nt)
+            continue;
+        if (gridDim.z > 1) { // K split across workgroups: fp32 partial tile -> this slice's slab (plain product: the reduce pass finishes)
+            *reinterpret_cast<f32x4 *>(arg_workspace + ((size_t)blockIdx.z * arg_m + m) * arg_n + ntile * 16 + g * 4) = v;
+        } else if (arg_act) {
+            if constexpr (NT % 2 == 0) {
+                f32x4 u;
+                if constexpr (WK > 1) {
+                    u = red[item + MT * 64];
+#pragma unroll
+                    for (int q = 1; q < WK; ++q)
+                        u += red[q * kItems + item + MT * 64];
+                } else {
+                    u = acc[mt][nt + 1 < NT ? nt + 1 : nt];
+                }
+                const unsigned n_half = arg_n >> 1, n = (ntile >> 1) * 16 + g * 4;
+                *reinterpret_cast<uint2 *>((char *)arg_c + ((size_t)m * n_half + n) * 2) = finish4_silu_mul<AT>(v, u, gs, arg_bias, n, n_half);
+            }
+        } else {
+            const unsigned n = ntile * 16 + g * 4;
+            *reinterpret_cast<uint2 *>((char *)arg_c + ((size_t)m * arg_n + n) * 2) = finish4<AT>(v, gs, arg_bias, n);
+        }
+    }
+}
+
+} // namespace petit_amd

@@ -16,7 +16,8 @@
 //   bits 32-35  mfma_type         0 fp16, 1 bf16            (MatmulMfmaType)
 //   bits 36-39  warp_partition_m  1; 2 = the 5 <= M <= 16 kernel whose WN waves of a K part share one
 //                                 activation tile in LDS (gemm_mid.hpp; warp_partition = 10 / 11 as the
-//                                 staged streaming kernels: 8 / 16 rows)
+//                                 staged streaming kernels: 8 / 16 rows), and with warp_partition = 0 the same
+//                                 organisation for 17 <= M <= 128 (gemm_batch.hpp: tile_m = MT m-tiles per workgroup)
 //   bits 40-43  warp_partition_n  WN
 //   bits 44-47  warp_partition_k  WK
 //   bits 48-51  warp_partition    the reference's NK(0)/Cooperative(1) enum, never 1 in
@@ -130,6 +131,9 @@ PETIT_DECLARE_PARTS(nv_f16)
 PETIT_DECLARE_PARTS(mx_bf16)
 PETIT_DECLARE_PARTS(mx_f16)
 #undef PETIT_DECLARE_PARTS
+const SolutionEntry *solutions_nv_bf16_p6(int *); // batched decode (gemm_batch.hpp); fp16 x MXFP4 has none yet (its kernels carry an exact fallback body)
+const SolutionEntry *solutions_nv_f16_p6(int *);
+const SolutionEntry *solutions_mx_bf16_p6(int *);
 const SolutionEntry *solutions_mx_bf16_p5(int *); // native FP4 MFMA kernels: MXFP4 weights only
 const SolutionEntry *solutions_mx_f16_p5(int *);
 // the activation quantiser of the 32x32x64 native kernels, stand-alone (gemm_mx_{bf16,f16}.hip): format 8 = MXFP8, 4 = MXFP4

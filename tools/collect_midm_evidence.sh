@@ -5,6 +5,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$R/gpurun_out/r05_midm}
 mkdir -p $OUT
+OUT=$(cd $OUT && pwd)   # (rocprofv3 runs from /tmp)
 cd /tmp && export TMPDIR=/tmp
 ARGS=""
 for spec in "o_m32 32 8192 8192" "o_m64 64 8192 8192" "qkv_m32 32 10240 8192" "qkv_m64 64 10240 8192" ${EXTRA_SPECS}; do
