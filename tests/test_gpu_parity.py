@@ -414,6 +414,36 @@ def test_every_solution_vs_oracle(pk, kind, is_bf16, m, n, k):
         check_gemm(c, ref, is_bf16, sum_abs)
 
 
+BATCH_PROBLEMS = [(33, 272, 4096), (64, 96, 8192), (100, 160, 3072), (128, 64, 2048), (17, 48, 1536), (40, 64, 768), (130, 288, 5120), (44, 10240, 1024)]
+
+
+@pytest.mark.parametrize("m,n,k", BATCH_PROBLEMS)
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+def test_batch_kernels_every_shape_and_split(pk, kind, is_bf16, m, n, k):
+    """csrc/gemm_batch.hpp (17 <= M <= 128, round 5): every instance x cross-workgroup K split 1 / 2 / 4 on problems that exercise what is new in
+    it -- several m-blocks with a ragged last one, K ranges that do not divide over the WK parts x the slices (parts that idle through their
+    partners' barriers), every span size (K % 1024 / 512 / 256), ragged N, one wide N -- against the oracle, and every launch repeated: the counted
+    vmcnt + bare s_barrier protocol and the LDS reduction are deterministic by design, so any bit difference between two launches is a race."""
+    a, q, s, gs = random_problem(kind, m, n, k, 4242 + m + n + k, is_bf16)
+    ref = oracle_ref(kind, a, is_bf16, q, s, gs)
+    sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
+    h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+    batch = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF == 0 and (sid >> 36) & 0xF == 2]
+    assert len(batch) >= 2, "no batch kernel enumerated for this span size"
+    ran = 0
+    for sid in batch:
+        for splitk in (1, 2, 4):
+            sk = (sid & ~(0xF << 60)) | (splitk << 60)
+            first = run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sk)
+            check_gemm(first, ref, is_bf16, sum_abs)
+            for _ in range(2):
+                assert np.array_equal(run_case(pk, kind, a, is_bf16, q, s, gs, m, n, k, sk), first), f"{sk:#x}: launches differ"
+            ran += 1
+    assert ran == 3 * len(batch)
+
+
 # The problem sizes of the reference's own GEMM gtest list (fp4/gemm_fp4_fp16_rocm_test.cc:333-425): each
 # TEST_BF16(m, n, k, ...) runs TestGemm(m, lcm(n, 32), lcm(k, 256)); de-duplicated.  Its per-case tile shapes
 # have no meaning here -- every kernel this build enumerates for the problem is run instead.
