@@ -1308,9 +1308,10 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kOk;
     }
     if (s.am == 0 && s.wm == 2) {
-        snprintf(buf, len, "batch %sx%s ks%d mt%d nt%d wn%d wk%d d%d splitk%u  (wg tile %dx%d, %d threads: %d K parts reduced in LDS, activation tiles shared by %d waves)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks, s.mt, s.nt, s.wn, s.wk, s.d,
-                 solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * s.wk, s.wk, s.wn);
+        const int da = s.pa == 2 ? 1 : s.pa == 4 ? 2 : s.pa == 8 ? 4 : 0; // loader wave per K part, activation tiles DA steps ahead (0: none)
+        snprintf(buf, len, "batch %sx%s ks%d mt%d nt%d wn%d wk%d d%d da%d splitk%u  (wg tile %dx%d, %d threads: %d K parts reduced in LDS, activation tiles shared by %d waves%s)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks, s.mt, s.nt, s.wn, s.wk, s.d, da,
+                 solution_splitk(id), 16 * s.mt, 16 * s.wn * s.nt, 64 * (s.wn + (da ? 1 : 0)) * s.wk, s.wk, s.wn, da ? ", a loader wave per part" : "");
         return kOk;
     }
     snprintf(buf, len, "stream %sx%s ks%d mt%d nt%d wn%d wk%d d%d am%d splitk%u  (wg tile %dx%d, %d threads)",

@@ -29,20 +29,29 @@ namespace petit_amd {
 //   NT    n-tiles per wave
 //   WN,WK waves along N / K in the workgroup (the WN waves of a K part share its activation tiles)
 //   D     ring depth in k-tiles (W in VGPRs, A in LDS slots), divides KS
-template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_> struct BatchCfg {
+//   DA    0: every wave loads its slice of the activation tiles together with its weights (one load queue per wave: tile t + D is requested with
+//            the weights of t + D, ring of D + 1 LDS slots -- gemm_mid.hpp's protocol).  A wave's loads retire in order, so the wait for the NEXT
+//            activation tile also waits for every weight tile requested before it: the weight stream is never more than D steps deep, and D is
+//            bounded by the LDS the activation ring takes.
+//         > 0: a LOADER wave per K part requests the activation tiles DA steps ahead (ring of DA + 1 slots) and does nothing else; the compute
+//            waves request weights only, D tiles deep per n-tile (hipcc tracks their vmcnt: no manual waits), and meet the loader at the step's
+//            barrier.  Weight bytes in flight per CU: WN WK NT D KiB, independent of the activation ring.
+template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int D_, int DA_ = 0> struct BatchCfg {
     using AT = AT_;
-    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_;
-    static constexpr int kThreads = 64 * WN * WK;
+    static constexpr int FMT = FMT_, KS = KS_, MT = MT_, NT = NT_, WN = WN_, WK = WK_, D = D_, DA = DA_;
+    static constexpr int kComputeWaves = WN * WK;
+    static constexpr int kThreads = 64 * (WN + (DA > 0 ? 1 : 0)) * WK;  // loader wave of part wk: wave kComputeWaves + wk
     static constexpr int BM = 16 * MT;
     static constexpr int kTileU4 = BM * 16;               // one activation tile: BM rows x 16 units of 16 B
-    static constexpr int kSlots = D + 1;
+    static constexpr int kSlots = (DA > 0 ? DA : D) + 1;
     static constexpr int kPartU4 = kSlots * kTileU4;      // per K part
-    static constexpr int kDma = BM * 16 / 64 / WN;        // KiB wave-loads per wave per tile
+    static constexpr int kDma = DA > 0 ? BM * 16 / 64 : BM * 16 / 64 / WN;   // KiB wave-loads per (loading) wave per tile
     static constexpr int kRedU4 = WN * NT * MT * 64;      // float4 partial outputs per K part
     // the reduction scratch reuses the activation ring (every wave has left the loop before the first partial sum is parked)
     static constexpr int kSmemU4 = WK * kPartU4 > WK * kRedU4 ? WK * kPartU4 : WK * kRedU4;
     static_assert(MT >= 2 && MT <= 8, "2..8 m-tiles: 32..128 rows");
-    static_assert(kDma >= 1 && kDma * WN * 4 == BM, "the waves of a K part split a tile into whole KiB loads");
+    static_assert(DA > 0 || (kDma >= 1 && kDma * WN * 4 == BM), "the waves of a K part split a tile into whole KiB loads");
+    static_assert(DA == 0 || (DA <= 4 && (DA > 1 ? (DA - 1) * kDma : 0) <= 63), "the loader's counted vmcnt is a 6-bit field");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(!AT::kBfp && !AT::kAdaptive, "plain bf16 / fp16 activations");
     static_assert(kThreads <= 1024 && kSmemU4 * 16 <= 160 * 1024, "workgroup / LDS budget");
@@ -55,7 +64,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
                                                                    float *arg_workspace) {
     using AT = typename Cfg::AT;
     using Frag = typename AT::frag;
-    constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT, WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D;
+    constexpr int FMT = Cfg::FMT, KS = Cfg::KS, MT = Cfg::MT, NT = Cfg::NT, WN = Cfg::WN, WK = Cfg::WK, D = Cfg::D, DA = Cfg::DA;
     constexpr unsigned kRecBytes = ScaleRec<FMT, KS>::kBytes;
     constexpr unsigned kOob = 0x80000000u;
     // loads a wave issues per step: its slice of the A tile + one W tile per n-tile
@@ -65,7 +74,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
 
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned wn = wave % WN, wk = wave / WN;
+    const bool loader = DA > 0 && wave >= (unsigned)Cfg::kComputeWaves;                       // (wave-uniform)
+    const unsigned wn = loader ? 0u : wave % WN, wk = loader ? wave - Cfg::kComputeWaves : wave / WN;
     const unsigned r = lane & 15u, g = lane >> 4;
 
     const unsigned ktiles = arg_k / kTileK;
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
             acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 *const a_part = smem + wk * Cfg::kPartU4;
-    const unsigned valid_nt = nt0 < ntiles ? min((unsigned)NT, ntiles - nt0) : 0u;
+    const unsigned valid_nt = (nt0 < ntiles && !loader) ? min((unsigned)NT, ntiles - nt0) : 0u;
     const unsigned w_row_bytes = ktiles * kTileBytes;
     const unsigned s_row_bytes = (FMT == kFmtNv) ? arg_k : arg_k / 2;
     const unsigned rows = min(arg_m - m0, (unsigned)Cfg::BM);
@@ -106,10 +116,12 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
     }
     // A tile slice of this wave: wave-load i covers rows 4 (i WN + wn) .. + 3; lane l -> row + l / 16, position l % 16, which receives
     // unit (l % 16) ^ (row % 16) of that row.  Rows >= M fall out of the descriptor: zeros.
+    // (DA > 0: the part's loader wave takes the whole tile: wave-load i covers rows 4 i .. 4 i + 3)
+    constexpr unsigned kDmaStride = DA > 0 ? 1u : (unsigned)WN;
     unsigned dma_voff[Cfg::kDma];
 #pragma unroll
     for (int i = 0; i < Cfg::kDma; ++i) {
-        const unsigned row = 4 * (i * WN + wn) + (lane >> 4);
+        const unsigned row = 4 * (i * kDmaStride + wn) + (lane >> 4);
         dma_voff[i] = row * arg_k * 2 + (((lane & 15u) ^ (row & 15u)) * 16);
     }
     auto dma_a_tile = [&](unsigned slot, unsigned kt) {
@@ -117,7 +129,7 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
         for (int i = 0; i < Cfg::kDma; ++i) {
 #if defined(__HIP_DEVICE_COMPILE__) // (the host pass knows neither the builtin nor the LDS address space)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                a_rsrc, (__attribute__((address_space(3))) void *)(a_part + slot * Cfg::kTileU4 + (i * WN + wn) * 64), 16, dma_voff[i],
+                a_rsrc, (__attribute__((address_space(3))) void *)(a_part + slot * Cfg::kTileU4 + (i * kDmaStride + wn) * 64), 16, dma_voff[i],
                 kt * 256, 0, 0);
 #else
             (void)slot, (void)kt;
@@ -131,7 +143,111 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
         fptr[j] = a_part + (int)(r * 16 + ((g * 4 + j) ^ r));
 
     const bool part_on = sp_begin < sp_end;
-    if (part_on) {
+    if constexpr (DA > 0) {
+        if (loader) {
+            // ---- the part's loader wave: activation tiles only, DA steps ahead.  Rolled loops: the trip count is the part's, the wait counts are
+            // constants (a tile is kDma loads; tile t + 1 is complete when at most the DA - 1 tiles requested after it are outstanding).
+            if (part_on) {
+                const unsigned kt_begin = sp_begin * KS, kt_end = sp_end * KS; // (>= KS >= DA tiles)
+                unsigned slot = kt_begin % Cfg::kSlots;
+                for (unsigned i = 0; i < (unsigned)DA; ++i)
+                    dma_a_tile((slot + i) % Cfg::kSlots, kt_begin + i);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * Cfg::kDma) : "memory");
+                __builtin_amdgcn_s_barrier();
+                unsigned kt = kt_begin;
+                for (; kt + DA < kt_end; ++kt) { // step kt: request tile kt + DA into the slot step kt - 1 read; tile kt + 1 must land
+                    dma_a_tile(slot == 0 ? (unsigned)DA : slot - 1, kt + DA);
+                    slot = slot + 1 == (unsigned)Cfg::kSlots ? 0u : slot + 1;
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * Cfg::kDma) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                for (; kt < kt_end; ++kt) { // the last DA steps request nothing: drain (nothing may be in flight when the ring's memory is reused)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+        } else if (part_on) {
+            // ---- a compute wave: weights only in its load queue, D tiles per n-tile in flight
+            const unsigned kt_begin = sp_begin * KS;
+            ScaleRec<FMT, KS> srec[NT], srec_next[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                srec[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], sp_begin * 64 * kRecBytes);
+            u32x4 wring[D][NT];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxNt);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // the loader's first tile is in its slot
+            asm volatile("" ::: "memory");
+            unsigned aslot = kt_begin % Cfg::kSlots;
+            auto span_body = [&](const unsigned sp, auto last_c) {
+                constexpr bool kLast = decltype(last_c)::value;
+                const unsigned kt0 = sp * KS;
+                if constexpr (!kLast) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        srec_next[nt] = load_scale_rec<FMT, KS>(s_rsrc, s_voff[nt], (sp + 1) * 64 * kRecBytes);
+                }
+                static_for<0, KS>([&](auto t_c) {
+                    constexpr int T = decltype(t_c)::value;
+                    constexpr int SLOT = T % D;
+                    constexpr bool kAhead = !kLast || (T + D < KS);
+                    const unsigned kt = kt0 + T;
+                    const unsigned cur = aslot * Cfg::kTileU4;
+                    aslot = aslot + 1 == (unsigned)Cfg::kSlots ? 0u : aslot + 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    Frag wf[NT][4];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float s_lo, s_hi;
+                        tile_scales<FMT, KS, T>(srec[nt], s_lo, s_hi);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned w = wring[SLOT][nt][j];
+                            if constexpr (FMT == kFmtNv)
+                                wf[nt][j] = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
+                            else
+                                wf[nt][j] = unpack_mx(AT{}, w, s_lo);
+                        }
+                    }
+                    if constexpr (kAhead) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxNt);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        Frag af[MT];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            af[mt] = __builtin_bit_cast(Frag, fptr[j][cur + mt * 256]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = mfma16(wf[nt][j], af[mt], acc[mt][nt]);
+                    }
+                    // the step's fragment reads must have RETURNED before the loader may overwrite that slot (their MFMAs usually forced that already;
+                    // nothing keeps hipcc from sinking an MFMA below the barrier, so say it); the weight loads stay in flight across the barrier
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr (!kLast) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        srec[nt] = srec_next[nt];
+                }
+            };
+            for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+                span_body(sp, std::false_type{});
+            span_body(sp_end - 1, std::true_type{});
+        }
+    } else if (part_on) {
         const unsigned kt_begin = sp_begin * KS;
         // --- prologue: D steps of loads, oldest first (A slice, then W, per step)
         ScaleRec<FMT, KS> srec[NT], srec_next[NT];
@@ -235,13 +351,17 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
     f32x4 *const red = reinterpret_cast<f32x4 *>(smem);
     constexpr int kItems = Cfg::kRedU4; // per K part: [(wn NT + nt) MT + mt][lane]
     if constexpr (WK > 1) {
+        if (!loader) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                red[wk * kItems + ((wn * NT + nt) * MT + mt) * 64 + lane] = acc[mt][nt];
+                for (int nt = 0; nt < NT; ++nt)
+                    red[wk * kItems + ((wn * NT + nt) * MT + mt) * 64 + lane] = acc[mt][nt];
+        }
         __syncthreads();
     }
+    if (loader)
+        return;
     const float gs = *arg_gs;
     // every thread finishes a share of the workgroup's (tile, lane) items: with WK parts each wave takes 1 / WK of ITS OWN tiles' items
     // (the other parts' copies of the same item come from LDS), so the stores stay 8 bytes per lane, 16 rows x 32 B per instruction

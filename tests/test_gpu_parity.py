@@ -424,6 +424,8 @@ def test_batch_kernels_every_shape_and_split(pk, kind, is_bf16, m, n, k):
     it -- several m-blocks with a ragged last one, K ranges that do not divide over the WK parts x the slices (parts that idle through their
     partners' barriers), every span size (K % 1024 / 512 / 256), ragged N, one wide N -- against the oracle, and every launch repeated: the counted
     vmcnt + bare s_barrier protocol and the LDS reduction are deterministic by design, so any bit difference between two launches is a race."""
+    if kind == "mx" and n % 32:
+        n += 16          # the MX scale tensor contract needs N % 32
     a, q, s, gs = random_problem(kind, m, n, k, 4242 + m + n + k, is_bf16)
     ref = oracle_ref(kind, a, is_bf16, q, s, gs)
     sum_abs = oracle_sum_abs(kind, a, is_bf16, q, s, gs)
@@ -431,7 +433,7 @@ def test_batch_kernels_every_shape_and_split(pk, kind, is_bf16, m, n, k):
     h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
     h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
     batch = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF == 0 and (sid >> 36) & 0xF == 2]
-    assert len(batch) >= 2, "no batch kernel enumerated for this span size"
+    assert len(batch) >= 4 and any((sid >> 21) & 7 for sid in batch) and any((sid >> 21) & 7 == 0 for sid in batch), "both forms (with / without a loader wave)"
     ran = 0
     for sid in batch:
         for splitk in (1, 2, 4):
@@ -2366,6 +2368,133 @@ def test_stacked_mlp_accuracy_budget(pk):
     assert report["mxfp8"]["rms_err_over_rms_of_update"] <= 0.15
     assert report["mxfp6"]["rms_err_over_rms_of_update"] <= 0.15
     assert report["mxfp4"]["rms_err_over_rms_of_update"] <= 0.8
+
+
+def _checkpoint_like_layer(pk, fmt, n, k, seed):
+    """tools/quantize_weights.py: bf16 weights ~ N(0, 1/K) with heavy-tailed rows and outliers -> NVFP4 / MXFP4 by the checkpoint recipe; returns the
+    original weights (f64), the dequantised ones (f64, incl. the global scale), the packed device tensors and the global scale."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import quantize_weights as QW
+    w = QW.synthetic_weights(n, k, seed)
+    q, sb, gs = (QW.quantize_nvfp4 if fmt == "nvfp4" else QW.quantize_mxfp4)(w)
+    qd = torch.from_numpy(q).to(DEV).view(torch.int32)
+    if fmt == "nvfp4":
+        b, sp = pk.repack_nvfp4(qd, n, k), pk.process_nvfp4_scales(torch.from_numpy(sb).to(DEV).view(torch.float8_e4m3fn), n, k)
+        assert np.array_equal(QW.dequantize(fmt, q, sb, 1.0), O.dequant_nvfp4(q, sb).astype(np.float64))      # the tool's dequant IS the oracle's
+    else:
+        b, sp = pk.repack_mxfp4(qd, n, k), pk.process_mxfp4_scales(torch.from_numpy(sb).to(DEV), n, k)
+        assert np.array_equal(QW.dequantize(fmt, q, sb, 1.0), O.dequant_mxfp4(q, sb).astype(np.float64))
+    return w.astype(np.float64), QW.dequantize(fmt, q, sb, gs), b, sp, torch.tensor([gs], dtype=torch.float32, device=DEV), QW.stats(fmt, w, q, sb, gs)
+
+
+def _rel_rms(a, b, denom):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / denom)
+
+
+def test_mlp_block_accuracy_budget_checkpoint_like_weights(pk):
+    """VERDICT r04 item 5 / the reference's model-level claim (README.md:3: MMLU 82.15 -> 80.79): the MLP-block budget on weights that look like a
+    checkpoint -- bf16 weights N(0, 1/K) with heavy-tailed rows, quantised by tools/quantize_weights.py (the nvidia/*-FP4 recipe for NVFP4, OCP MX
+    for MXFP4) -- instead of uniformly random nibbles.  Two errors are kept apart, both relative to the rms of the bf16-weight block's output:
+      weight quantisation      the exact FP4 GEMM path against the bf16-WEIGHT block (what the reference's 82.15 -> 80.79 measures), per weight format;
+      activation quantisation  the native classes against the exact FP4 path on the same MXFP4 weights (what opting into -2 / -4 / -3 adds)."""
+    import json
+    hid, inter, m = 2048, 4096, 96
+    rng = np.random.default_rng(2027)
+    x = rng.standard_normal((m, hid), dtype=np.float32)
+    x[:, rng.choice(hid, 6, replace=False)] *= 60.0
+    x_bits = O.f32_to_bf16_bits(x)
+    xf = to_f32(x_bits, True).astype(np.float64)
+    xd = from_bits(x_bits, torch.bfloat16).to(DEV)
+
+    def block(w1, w2, g=1.0):
+        y1 = xf @ w1.T
+        return (y1[:, :inter] / (1.0 + np.exp(-y1[:, :inter])) * y1[:, inter:]) @ w2.T
+
+    report, wstats = {}, {}
+    ref_bf16 = None
+    for fmt in ("nvfp4", "mxfp4"):
+        w1, dq1, b1, sp1, g1, st1 = _checkpoint_like_layer(pk, fmt, 2 * inter, hid, 31)
+        w2, dq2, b2, sp2, g2, st2 = _checkpoint_like_layer(pk, fmt, hid, inter, 32)
+        wstats[fmt] = {"gate_up": st1, "down": st2}
+        if ref_bf16 is None:
+            ref_bf16 = block(w1, w2)
+        rms = np.sqrt(np.mean(ref_bf16 ** 2))
+        ref_fp4 = block(dq1, dq2)
+        mul = pk.mul_nvfp4_a16 if fmt == "nvfp4" else pk.mul_mxfp4_a16
+        h1 = mul(xd, b1, sp1, g1, m, 2 * inter, hid, -1, activation="silu_mul")
+        y = mul(h1, b2, sp2, g2, m, hid, inter, -1).float().cpu().numpy().astype(np.float64)
+        report[f"exact_{fmt}"] = {"weight_quantisation_oracle": _rel_rms(ref_fp4, ref_bf16, rms), "gpu_vs_fp4_oracle": _rel_rms(y, ref_fp4, rms),
+                                  "gpu_vs_bf16_weight_block": _rel_rms(y, ref_bf16, rms)}
+        if fmt == "mxfp4":
+            for act, sid in (("mxfp8", pk.SOLUTION_AUTO_NATIVE_MXFP8), ("mxfp6", pk.SOLUTION_AUTO_NATIVE_MXFP6), ("mxfp4", pk.SOLUTION_AUTO_NATIVE_MXFP4)):
+                hq = pk.mul_mxfp4_native(pk.quantize_activations(xd, act), b1, sp1, g1, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=act)
+                yn = pk.mul_mxfp4_native(hq, b2, sp2, g2, m, hid, inter, sid).float().cpu().numpy().astype(np.float64)
+                report[f"native_{act}"] = {"activation_quantisation_vs_exact_fp4": _rel_rms(yn, ref_fp4, rms), "total_vs_bf16_weight_block": _rel_rms(yn, ref_bf16, rms)}
+    print("mlp block accuracy budget (checkpoint-like weights):", json.dumps(report))
+    dump = ROOT / "gpurun_out"
+    if dump.is_dir():
+        (dump / "mlp_accuracy_budget_checkpoint_like.json").write_text(json.dumps({"hidden": hid, "intermediate": inter, "m": m, "outlier_columns": 6, "outlier_factor": 60,
+                                                                                    "weights": wstats, "errors_relative_to_rms_of_bf16_weight_block": report}, indent=1))
+    for fmt in ("nvfp4", "mxfp4"):
+        assert report[f"exact_{fmt}"]["gpu_vs_fp4_oracle"] <= 1e-2                     # the exact path IS the FP4 model
+        assert 0.02 <= report[f"exact_{fmt}"]["weight_quantisation_oracle"] <= 0.35     # (a 4-bit weight format costs something: ~10 % per weight)
+    assert report["native_mxfp8"]["activation_quantisation_vs_exact_fp4"] <= 8e-2
+    assert report["native_mxfp6"]["activation_quantisation_vs_exact_fp4"] <= 0.11
+    assert report["native_mxfp4"]["activation_quantisation_vs_exact_fp4"] <= 0.45
+    # the deployable classes add less than the weight format already costs
+    assert report["native_mxfp8"]["activation_quantisation_vs_exact_fp4"] < report["exact_mxfp4"]["weight_quantisation_oracle"]
+
+
+def test_stacked_mlp_accuracy_budget_checkpoint_like_weights(pk):
+    """The stacked budget (four pre-norm residual MLP layers, hidden 1024, intermediate 2048, 64 tokens, outlier channels) on checkpoint-like MXFP4
+    weights: per path the rms error of the update the four layers add to the residual stream -- against the bf16-WEIGHT stack (weight + activation
+    quantisation) and against the exact-FP4 stack (activation quantisation alone)."""
+    import json
+    hid, inter, m, layers = 1024, 2048, 64, 4
+    rng = np.random.default_rng(78)
+    x0 = rng.standard_normal((m, hid)).astype(np.float32)
+    x0[:, rng.choice(hid, 4, replace=False)] *= 40.0
+    L = [(_checkpoint_like_layer(pk, "mxfp4", 2 * inter, hid, 700 + i), _checkpoint_like_layer(pk, "mxfp4", hid, inter, 800 + i)) for i in range(layers)]
+    gain = 8.0       # (N(0, 1/K) weights behind an rmsnorm would add a negligible update: scale the MLP output so that the layers matter)
+
+    def rmsnorm(x):
+        return x / np.sqrt((x * x).mean(axis=1, keepdims=True) + 1e-6)
+
+    def stack(which):
+        r = x0.astype(np.float64)
+        for l1, l2 in L:
+            y = rmsnorm(r) @ l1[which].T * gain
+            r = r + (y[:, :inter] / (1.0 + np.exp(-y[:, :inter])) * y[:, inter:]) @ l2[which].T * gain
+        return r
+    ref_bf16, ref_fp4 = stack(0), stack(1)
+    upd = np.sqrt(np.mean((ref_bf16 - x0) ** 2))
+    report = {"weight_quantisation_oracle": _rel_rms(ref_fp4, ref_bf16, upd)}
+    for name in ("exact", "mxfp8", "mxfp6", "mxfp4"):
+        x = torch.from_numpy(x0).to(DEV)
+        for (_, _, b1, sp1, g1, _), (_, _, b2, sp2, g2, _) in L:
+            xn = (x / torch.sqrt((x * x).mean(dim=1, keepdim=True) + 1e-6)).bfloat16()
+            ga, gb = g1 * gain, g2 * gain
+            if name == "exact":
+                h = pk.mul_mxfp4_a16(xn, b1, sp1, ga, m, 2 * inter, hid, -1, activation="silu_mul")
+                d = pk.mul_mxfp4_a16(h, b2, sp2, gb, m, hid, inter, -1)
+            else:
+                sid = NATIVE_SENTINEL(pk, name)
+                hq = pk.mul_mxfp4_native(pk.quantize_activations(xn, name), b1, sp1, ga, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=name)
+                d = pk.mul_mxfp4_native(hq, b2, sp2, gb, m, hid, inter, sid)
+            x = x + d.float()
+        xe = x.cpu().numpy().astype(np.float64)
+        report[name] = {"vs_exact_fp4_stack_over_update": _rel_rms(xe, ref_fp4, upd), "vs_bf16_weight_stack_over_update": _rel_rms(xe, ref_bf16, upd)}
+    print("stacked mlp accuracy budget (checkpoint-like weights):", json.dumps(report))
+    dump = ROOT / "gpurun_out"
+    if dump.is_dir():
+        (dump / "stacked_mlp_accuracy_budget_checkpoint_like.json").write_text(json.dumps({"layers": layers, "hidden": hid, "intermediate": inter, "m": m, "outlier_columns": 4,
+                                                                                           "outlier_factor": 40, "mlp_gain": gain, "errors": report}, indent=1))
+    assert report["exact"]["vs_exact_fp4_stack_over_update"] <= 2e-2
+    assert report["mxfp8"]["vs_exact_fp4_stack_over_update"] <= 0.15
+    assert report["mxfp6"]["vs_exact_fp4_stack_over_update"] <= 0.15
+    assert report["mxfp4"]["vs_exact_fp4_stack_over_update"] <= 0.8
+    assert 0.02 <= report["weight_quantisation_oracle"] <= 0.6
 
 
 def test_examples_run(pk):
