@@ -20,6 +20,13 @@
 
 #include "device_common.hpp"
 
+// Ablation builds (tools/ablate_batch.sh; 0 in the shipped library): 1 no activation-tile DMA after the prologue, 2 no unpack VALU (the packed words
+// stand in for the fragments), 4 no MFMA, 8 no LDS fragment reads (one fragment per step stands in), 16 no weight refills.  Results are garbage; only
+// time counts.
+#ifndef PETIT_ABLATE_BATCH
+#define PETIT_ABLATE_BATCH 0
+#endif
+
 namespace petit_amd {
 
 //   AT    Bf16 / Fp16 activations (and output)
@@ -156,7 +163,8 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
                 __builtin_amdgcn_s_barrier();
                 unsigned kt = kt_begin;
                 for (; kt + DA < kt_end; ++kt) { // step kt: request tile kt + DA into the slot step kt - 1 read; tile kt + 1 must land
-                    dma_a_tile(slot == 0 ? (unsigned)DA : slot - 1, kt + DA);
+                    if constexpr (!(PETIT_ABLATE_BATCH & 1))
+                        dma_a_tile(slot == 0 ? (unsigned)DA : slot - 1, kt + DA);
                     slot = slot + 1 == (unsigned)Cfg::kSlots ? 0u : slot + 1;
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 1) * Cfg::kDma) : "memory");
                     __builtin_amdgcn_s_barrier();
@@ -207,13 +215,15 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const unsigned w = wring[SLOT][nt][j];
-                            if constexpr (FMT == kFmtNv)
+                            if constexpr (PETIT_ABLATE_BATCH & 2)
+                                wf[nt][j] = __builtin_bit_cast(Frag, u32x4{w, w ^ __builtin_bit_cast(unsigned, s_lo), w, __builtin_bit_cast(unsigned, s_hi)});
+                            else if constexpr (FMT == kFmtNv)
                                 wf[nt][j] = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
                             else
                                 wf[nt][j] = unpack_mx(AT{}, w, s_lo);
                         }
                     }
-                    if constexpr (kAhead) {
+                    if constexpr (kAhead && !(PETIT_ABLATE_BATCH & 16)) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxNt);
@@ -223,12 +233,18 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
                         Frag af[MT];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            af[mt] = __builtin_bit_cast(Frag, fptr[j][cur + mt * 256]);
+                            af[mt] = __builtin_bit_cast(Frag, fptr[(PETIT_ABLATE_BATCH & 8) ? 0 : j][cur + ((PETIT_ABLATE_BATCH & 8) ? 0 : mt * 256)]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = mfma16(wf[nt][j], af[mt], acc[mt][nt]);
+                            for (int nt = 0; nt < NT; ++nt) {
+                                if constexpr (PETIT_ABLATE_BATCH & 4) {
+                                    const u32x4 wb = __builtin_bit_cast(u32x4, wf[nt][j]), ab = __builtin_bit_cast(u32x4, af[mt]);
+                                    acc[mt][nt][j] += __builtin_bit_cast(float, wb[0] ^ ab[1]);
+                                } else {
+                                    acc[mt][nt] = mfma16(wf[nt][j], af[mt], acc[mt][nt]);
+                                }
+                            }
                     }
                     // the step's fragment reads must have RETURNED before the loader may overwrite that slot (their MFMAs usually forced that already;
                     // nothing keeps hipcc from sinking an MFMA below the barrier, so say it); the weight loads stay in flight across the barrier

@@ -8,8 +8,8 @@ mkdir -p $OUT
 OUT=$(cd $OUT && pwd)   # (rocprofv3 runs from /tmp)
 cd /tmp && export TMPDIR=/tmp
 ARGS=""
-for spec in "o_m32 32 8192 8192" "o_m64 64 8192 8192" "qkv_m32 32 10240 8192" "qkv_m64 64 10240 8192" ${EXTRA_SPECS}; do
-  set -- $spec
+for spec in "o_m32 32 8192 8192" "o_m64 64 8192 8192" "qkv_m32 32 10240 8192" "qkv_m64 64 10240 8192" ${EXTRA_SPECS}; do   # EXTRA_SPECS: tag:M:N:K ...
+  set -- ${spec//:/ }
   TAG=$1; M=$2; N=$3; K=$4
   SOLVAR=SOL_$TAG; SOL=${!SOLVAR:-auto}
   i=0
