@@ -118,13 +118,29 @@ struct Runner {
     }
 };
 
-// lane of (row-or-column 0, k-block `blk`): 32x32x64 has two 32-element blocks per operand row (lanes 0 and 32), 16x16x128 four (lanes 0, 16, 32, 48)
+// lane of (row-or-column 0, k-block `blk`): 32x32x64 has two 32-element blocks per operand row (lanes 0 and 32), 16x16x128 four (lanes 0, 16, 32, 48);
+// the E8M0 scale byte of block b comes from that lane, for every element format (csrc/gemm_native32.hpp, layout note)
 static int lane_of_block(int shape, int blk) { return shape == 32 ? 32 * blk : 16 * blk; }
-
-// one term: weight 1.0 (FP4) at (block, position) of row 0 of A; activation `code` at the same (block, position) of column 0 of B
-static void term(Operands &o, int shape, int fmt, int blk, int pos, float act) {
-    put(o.a, lane_of_block(shape, blk), pos, 4, enc(4, 1.0f));
-    put(o.b, lane_of_block(shape, blk), pos, bits_of(fmt), enc(fmt, act));
+// where element k of row / column 0 sits: FP4 and FP6 operands hold 32 consecutive k per lane (lane group = k / 32); an FP8 operand's lane group g holds
+// k = 16 g .. 16 g + 15 in registers 0-3 and HALF + 16 g .. HALF + 16 g + 15 in registers 4-7 (HALF = 32 for 32x32x64, 64 for 16x16x128): probed on gfx950
+// (tools/probes/mfma32_layout_probe.hip), and checked again by layout_selfcheck() below before anything is measured
+static void locate(int shape, int fmt, int k, int *lane, int *elem) {
+    const int step = shape == 32 ? 32 : 16, half = shape == 32 ? 32 : 64;
+    if (fmt != 0) {
+        *lane = step * (k / 32), *elem = k % 32;
+    } else if (k < half) {
+        *lane = step * (k / 16), *elem = k % 16;
+    } else {
+        *lane = step * ((k - half) / 16), *elem = 16 + (k - half) % 16;
+    }
+}
+// one term: weight `wgt` (FP4) at k of row 0 of A; activation `act` at k of column 0 of B
+static void term(Operands &o, int shape, int fmt, int k, float act, float wgt = 1.0f) {
+    int lane, elem;
+    locate(shape, 4, k, &lane, &elem);
+    put(o.a, lane, elem, 4, enc(4, wgt));
+    locate(shape, fmt, k, &lane, &elem);
+    put(o.b, lane, elem, bits_of(fmt), enc(fmt, act));
 }
 
 static double surviving_bits(double got, double exact, double small) {
@@ -138,6 +154,21 @@ static double surviving_bits(double got, double exact, double small) {
 int main() {
     Runner R;
     const char *fname[5] = {"fp8_e4m3", "", "fp6_e2m3", "", "fp4_e2m1"};
+    // layout self-check: every single k, alone, must contribute exactly its product (and its block's scales)
+    for (int shape : {32, 16})
+        for (int fmt : {0, 2, 4}) {
+            int bad = 0;
+            const int K = shape == 32 ? 64 : 128;
+            for (int k = 0; k < K; ++k) {
+                Operands o;
+                term(o, shape, fmt, k, 1.5f, 2.0f);
+                o.sb[lane_of_block(shape, k / 32)] = 127 + 3, o.sa[lane_of_block(shape, k / 32)] = 127 - 1;
+                const float got = R.run(o, shape, fmt);
+                if (got != 1.5f * 2.0f * 8.0f * 0.5f && bad++ < 4)
+                    printf("LAYOUT %dx%d %s k=%d: got %g want 12\n", shape, shape, fname[fmt], k, got);
+            }
+            printf("layout self-check %dx%d %s: %d of %d positions wrong\n", shape, shape, fname[fmt], bad, K);
+        }
     printf("# instr bfmt case gap_log2 big small c_in got exact bits_of_small_surviving\n");
     for (int shape : {32, 16}) {
         for (int fmt : {0, 2, 4}) {
@@ -156,9 +187,9 @@ int main() {
                         ok = true;
                 if (!ok)
                     continue;
-                for (int pos_small : {2, 31}) {
+                for (int pos_small : {2, 17, 31}) {
                     Operands o;
-                    term(o, shape, fmt, 0, 0, big), term(o, shape, fmt, 0, 1, -big), term(o, shape, fmt, 0, pos_small, small);
+                    term(o, shape, fmt, 0, big), term(o, shape, fmt, 1, -big), term(o, shape, fmt, pos_small, small);
                     const float got = R.run(o, shape, fmt);
                     const double gap = log2((double)big / small);
                     const double bits = surviving_bits(got, small, small);
@@ -171,7 +202,7 @@ int main() {
             for (int b = 1; b < nblk; ++b)
                 for (int G = 0; G <= 64; ++G) {
                     Operands o;
-                    term(o, shape, fmt, 0, 0, big), term(o, shape, fmt, 0, 1, -big), term(o, shape, fmt, b, 5, full);
+                    term(o, shape, fmt, 0, big), term(o, shape, fmt, 1, -big), term(o, shape, fmt, 32 * b + 5, full);
                     o.sb[lane_of_block(shape, 0)] = 127 + G; // activations of block 0 scaled by 2^G
                     const float got = R.run(o, shape, fmt);
                     const double gap = G + log2((double)big / full);
@@ -183,7 +214,7 @@ int main() {
             // ---- accumulator: +big, -big as products (scale 2^G), C = a full-mantissa f32
             for (int G = 0; G <= 64; ++G) {
                 Operands o;
-                term(o, shape, fmt, 0, 0, big), term(o, shape, fmt, 0, 1, -big);
+                term(o, shape, fmt, 0, big), term(o, shape, fmt, 1, -big);
                 o.sb[lane_of_block(shape, 0)] = 127 + G;
                 const float cin = 1.2345678f;
                 o.c[0] = cin;
@@ -199,7 +230,7 @@ int main() {
             for (int G = 0; G <= 30; ++G)
                 for (int b = 0; b < nblk; ++b) {
                     Operands o;
-                    term(o, shape, fmt, 0, 0, big), term(o, shape, fmt, b, 7, full);
+                    term(o, shape, fmt, 0, big), term(o, shape, fmt, 32 * b + 7, full);
                     o.sb[lane_of_block(shape, 0)] = 127 + G;
                     if (b == 0) { // same block: both scaled
                     }
