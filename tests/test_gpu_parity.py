@@ -1206,6 +1206,36 @@ def test_llama70b_fp16_mxfp4_full_size(pk, shape):
             P.check_sampled(P.run(a, False, sid), a, False, f"M={m} sid={sid:#x}")
 
 
+def native_exact_bound(a_q: np.ndarray, w: np.ndarray, gs: float) -> np.ndarray:
+    """Per-output bound on |kernel - exact| for the native (block-scaled MFMA) kernels, DERIVED from what the instruction does
+    (tools/probes/mfma_scale_align.hip, profiles/r05_mfma_scale_align.txt; include/petit_amd.h states it).  Inside v_mfma_scale_f32_*_f8f6f4 the
+    products of one pass (never more than one 32-element block: a term in ANOTHER block of the same instruction survives next to +-big at any gap) and
+    the incoming accumulator are aligned to the largest of them and every operand is TRUNCATED to a multiple of 2^(E - 24), E = floor(log2(largest
+    |operand|)) -- measured identically for FP8 / FP6 / FP4 activations and both instruction shapes; the sum of the aligned operands is then exact.
+    So a 32-element block contributes at most (32 + 1) * 2^(E_b - 24), E_b = floor(log2(max(largest |product| of the block, |running sum|))).  The
+    running sum of ANY accumulation order or K split is at most T = sum over blocks of |block sum|; the largest product of a block is at most
+    max|a| * max|w| over the block; the cross-wave / cross-slice f32 additions (K parts, K groups, split-K slabs: <= 16 of them) add 2^-24 T each.
+        bound = gs * ( 33 * sum_b 2^(floor(log2(max(amax_b * wmax_b, T))) - 24)  +  16 * 2^-24 * T )
+    a_q [m, K] (the quantised activations, dequantised), w [n, K] (dequantised weights without the global scale) -> [m, n]."""
+    m, k = a_q.shape
+    n = w.shape[0]
+    nb = k // 32
+    A = a_q.astype(np.float64).reshape(m, nb, 32)
+    W = w.astype(np.float64).reshape(n, nb, 32)
+    amax = np.abs(A).max(axis=2)
+    out = np.empty((m, n))
+    step = max(1, (8 << 20) // max(1, m * nb))                 # column chunks: [m, chunk, nb] stays under ~64 MB
+    for c0 in range(0, n, step):
+        Wc = W[c0:c0 + step]
+        bs = np.einsum("mbi,nbi->mnb", A, Wc, optimize=True)
+        T = np.abs(bs).sum(axis=2)
+        pmax = amax[:, None, :] * np.abs(Wc).max(axis=2)[None, :, :]
+        mx = np.maximum(np.maximum(pmax, T[:, :, None]), 1e-300)
+        unit = np.exp2(np.floor(np.log2(mx)) - 24.0)
+        out[:, c0:c0 + step] = 33.0 * unit.sum(axis=2) + 16.0 * 2.0 ** -24 * T
+    return abs(gs) * out
+
+
 def check_native_sampled(P, c, a_bits, act_code, tag):
     """A native-FP4 kernel's output on FullSizeProblem P's sampled columns: (1) exact semantics against the oracle run on the
     CPU-quantised activations (usual 1e-2 bound), (2) the class's stated end-to-end tolerance against the unquantised oracle
@@ -1217,12 +1247,12 @@ def check_native_sampled(P, c, a_bits, act_code, tag):
         a_q = {2: quantize_act_mxfp8, 4: quantize_act_mxfp6, 6: quantize_act_mxfp4}[act_code](a_f32)
         _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, P.dq, P.gs)
         _, full = O.gemm_ref(a_bits, True, P.dq, P.gs)
-        cache[key] = (exact, full, (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs)
-    exact, full, sum_abs = cache[key]
+        cache[key] = (exact, full, (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs, native_exact_bound(a_q, P.dq, P.gs))
+    exact, full, sum_abs, derived = cache[key]
     got = to_f32(bits(c[:, torch.from_numpy(P.rows).to(DEV)]), True).astype(np.float64)
     err = np.abs(got - exact)
-    cancel = 4e-5 if act_code == 2 else 1e-5      # (MXFP8: see test_native_mxfp4)
-    assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), cancel * sum_abs)).all(), f"{tag}: exact-semantics max err {err.max()}"
+    # (the derived per-output bound replaces rounds 3-4's empirical 1e-5 ... 4e-5 of sum|a||w|: native_exact_bound)
+    assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)).all(), f"{tag}: exact-semantics max err {err.max()}"
     coef = 2e-2 if act_code in (2, 4) else 0.12
     assert (np.abs(got - full) <= coef * sum_abs + 1e-2).all(), f"{tag}: class tolerance"
 
@@ -1634,13 +1664,14 @@ def test_native_fp4_activations(pk, m, n, k, is_bf16):
         _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq, gs)       # (4 significant bits x power of two: exact in bf16)
         _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)
         sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        derived = native_exact_bound(a_q, dq, gs)          # (the bound derived from the instruction: see native_exact_bound)
         fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
         for sid in fp4:
             for splitk in (1, 2):
                 sk = (sid & ~(0xF << 60)) | (splitk << 60)
                 c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sk), is_bf16).astype(np.float64)
                 err = np.abs(c - exact)[fin]
-                assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all(), f"{sk:#x} max {err.max()}"
+                assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all(), f"{sk:#x} max {err.max()}"
                 assert (np.abs(c - full)[fin] <= 0.12 * sum_abs[fin] + 1e-2).all(), f"{sk:#x}"
                 assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 0.25 * np.sqrt(np.mean(full[fin] ** 2)), f"{sk:#x}"
     finally:
@@ -1691,13 +1722,14 @@ def test_native_mxfp6_activations(pk, m, n, k, is_bf16):
         _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq, gs)       # (5 significant bits x power of two: exact in bf16)
         _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)
         sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        derived = native_exact_bound(a_q, dq, gs)          # (the bound derived from the instruction: see native_exact_bound)
         fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
         for sid in fp6:
             for splitk in (1, 2):
                 sk = (sid & ~(0xF << 60)) | (splitk << 60)
                 c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sk), is_bf16).astype(np.float64)
                 err = np.abs(c - exact)[fin]
-                assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all(), f"{sk:#x} max {err.max()}"
+                assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all(), f"{sk:#x} max {err.max()}"
                 assert (np.abs(c - full)[fin] <= 2e-2 * sum_abs[fin] + 1e-2).all(), f"{sk:#x}"
                 assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 6e-2 * np.sqrt(np.mean(full[fin] ** 2)), f"{sk:#x}"
         # the class sentinel on its own entry point: an enumerated kernel of the class, same numbers
@@ -1707,7 +1739,7 @@ def test_native_mxfp6_activations(pk, m, n, k, is_bf16):
         gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
         ad = from_bits(a_bits, h.a_type).to(DEV)
         c_auto = to_f32(bits(pk.mul_mxfp4_native(ad, b, sp, gsd, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP6)), is_bf16).astype(np.float64)
-        assert (np.abs(c_auto - exact)[fin] <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 1e-5 * sum_abs)[fin]).all()
+        assert (np.abs(c_auto - exact)[fin] <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all()
         # pre-quantised activations (one launch) are bit-identical to quantising inside the call
         qa = pk.quantize_activations(ad, "mxfp6")
         c_pre = pk.mul_mxfp4_native(qa, b, sp, gsd, m, n, k, fp6[0])
@@ -1752,15 +1784,15 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
         _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq, gs)               # same quantised activations
         _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)                              # unquantised activations
         sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        derived = native_exact_bound(a_q, dq, gs)
         for sid in native:
             c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sid), is_bf16).astype(np.float64)
             fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
-            # (1) the kernel computes exactly "MXFP8(activations) x MXFP4(weights)": only the f32
-            #     accumulation order and the final 16-bit rounding separate it from the oracle.  (4e-5 of sum|a||w| where the terms cancel: the
-            #     FP8-rate MFMA aligns the products of a k-group to the largest one -- tools/fuzz_parity.py, profiles/r04_fuzz.txt: 12 elements in
-            #     9 854 random problems between 1.0 and 2.1 x the 1e-5 the other classes keep, each where |result| < sum|a||w| / 400; twice the worst seen.)
+            # (1) the kernel computes exactly "MXFP8(activations) x MXFP4(weights)": only the accumulation inside and between the block-scaled MFMAs and
+            #     the final 16-bit rounding separate it from the oracle -- bounded per output by native_exact_bound (derived from the instruction; rounds
+            #     3-4 carried an empirical 1e-5 -> 2e-5 -> 4e-5 of sum|a||w| here, raised whenever a fuzz run found a worse element)
             err = np.abs(c - exact)[fin]
-            assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 4e-5 * sum_abs)[fin]).all()
+            assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all()
             # (2) stated tolerance of the path against the UNQUANTISED reference: e4m3 activations carry
             #     up to 2^-4 relative error each; on these random problems the result stays within 2 %
             #     of sum|a||w| (and typically ~3 % of the output's rms)

@@ -26,10 +26,18 @@ from petit_kernel import _lib  # noqa: E402
 from build_table import HELDOUT  # noqa: E402
 from table_from_candidates import read  # noqa: E402
 
-data = Path(sys.argv[sys.argv.index("--data") + 1]) if "--data" in sys.argv else ROOT / "profiles" / "r04_table_candidates.csv.gz"
-best, cands = read(data)
+# --data FILE [--data FILE ...]: tuner logs, oldest first; a problem (dtypes, M, N, K) timed in a later log is taken from THAT log alone (a newer
+# library has kernels the older log never timed).  Default: the round-4 full log, then round 5's held-out log (every M bucket incl. prefill, the
+# batched-decode kernels in).
+datas = [Path(sys.argv[i + 1]) for i, a in enumerate(sys.argv) if a == "--data"] or \
+        [p for p in (ROOT / "profiles" / "r04_table_candidates.csv.gz", ROOT / "profiles" / "r05_heldout_candidates.csv.gz") if p.exists()]
+best, cands = {}, {}
+for data in datas:
+    b, c = read(data)
+    best.update(b)
+    cands.update(c)
 only_held = "--heldout" in sys.argv
-BUCKETS = [(1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 64), (65, 128), (129, 256), (257, 1 << 20)]
+BUCKETS = [(1, 1), (2, 2), (3, 4), (5, 8), (9, 16), (17, 32), (33, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 4096), (4097, 1 << 20)]
 rows, missing = [], []
 for (at, bt, klass, m, n, k), (bsid, bus) in sorted(best.items()):
     if klass != 0 or ((n, k) in HELDOUT) != only_held:
