@@ -292,6 +292,16 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
  * by petit_gemm_get_solutions after petit_enable_native_fp4(1) (or $PETIT_AMD_NATIVE_FP4=1).  Their
  * ids carry mfma_type = 2 (the reference's unused kMatmulMfmaTypeFp8, gemm.h:20-24).  They need a
  * registered workspace of petit_native_workspace_bytes(m, k) bytes for the quantised activations.
+ *
+ * Exactness of the class, given the quantised activations (derived from the instruction, not fitted: tools/probes/mfma_scale_align.hip,
+ * profiles/r05_mfma_scale_align.txt).  Inside v_mfma_scale_f32_{32x32x64,16x16x128}_f8f6f4 the products of one pass -- never more than one
+ * 32-element block -- and the incoming accumulator are aligned to the largest of them, and every operand is TRUNCATED to a multiple of
+ * 2^(E - 24), E = floor(log2(largest |operand|)); their sum is then exact (the same for FP8 / FP6 / FP4 activations and both shapes; a term in
+ * another block of the same instruction survives beside +-big of any size).  With P_b the largest |a w| of block b, T the sum over blocks of
+ * |block sum| (no accumulation order or K split has a larger partial sum) and gs the global scale, every output satisfies
+ *     |c - exact| <= gs * ( 33 * sum_b 2^(floor(log2(max(P_b, T))) - 24) + 16 * 2^-24 * T )  +  one 16-bit rounding,
+ * about 1e-4 of sum |a w| at K = 8192 in the worst case, far below 1 % of the result unless the terms cancel to < 1 % of their size.  The tests
+ * (tests/test_gpu_parity.py native_exact_bound) and tools/fuzz_parity.py hold every native kernel to it.
  */
 int petit_enable_native_fp4(int enable);
 uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);

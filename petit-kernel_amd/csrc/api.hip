@@ -697,8 +697,8 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         // (measured: down 8192 x 28672 at M = 16, staged 16 x 64 tiles with a K split of 2: 29.0 us against 30.5 unsplit -- every CU
         // then pulls half of the activations)
         const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1) || is_batch(e);
-        if (is_batch(e) && m > 256)
-            continue; // (32-128-row workgroups that each stream their whole column block: never a candidate for prefill)
+        if (is_batch(e) && (m > 256 || m > 8u * 16u * (unsigned)s.mt))
+            continue; // (16-128-row workgroups that each stream their whole column block: never a candidate for prefill, or beyond eight m-blocks)
         if (!splittable)
             continue;
         for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)

@@ -56,7 +56,7 @@ template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int 
     static constexpr int kRedU4 = WN * NT * MT * 64;      // float4 partial outputs per K part
     // the reduction scratch reuses the activation ring (every wave has left the loop before the first partial sum is parked)
     static constexpr int kSmemU4 = WK * kPartU4 > WK * kRedU4 ? WK * kPartU4 : WK * kRedU4;
-    static_assert(MT >= 2 && MT <= 8, "2..8 m-tiles: 32..128 rows");
+    static_assert(MT >= 1 && MT <= 8 && (MT >= 2 || DA > 0), "1..8 m-tiles (MT = 1 without a loader wave is gemm_mid.hpp)");
     static_assert(DA > 0 || (kDma >= 1 && kDma * WN * 4 == BM), "the waves of a K part split a tile into whole KiB loads");
     static_assert(DA == 0 || (DA <= 4 && (DA > 1 ? (DA - 1) * kDma : 0) <= 63), "the loader's counted vmcnt is a 6-bit field");
     static_assert(KS % D == 0, "ring depth must divide the span");
