@@ -49,7 +49,7 @@ static const SolutionEntry *concat_parts(std::vector<SolutionEntry> &store, std:
 PETIT_FAMILY_TABLE(nv_bf16, solutions_nv_bf16_p1, solutions_nv_bf16_p2, solutions_nv_bf16_p3, solutions_nv_bf16_p4, solutions_nv_bf16_p6)
 PETIT_FAMILY_TABLE(nv_f16, solutions_nv_f16_p1, solutions_nv_f16_p2, solutions_nv_f16_p3, solutions_nv_f16_p4, solutions_nv_f16_p6)
 PETIT_FAMILY_TABLE(mx_bf16, solutions_mx_bf16_p1, solutions_mx_bf16_p2, solutions_mx_bf16_p3, solutions_mx_bf16_p4, solutions_mx_bf16_p5, solutions_mx_bf16_p6)
-PETIT_FAMILY_TABLE(mx_f16, solutions_mx_f16_p1, solutions_mx_f16_p2, solutions_mx_f16_p3, solutions_mx_f16_p4, solutions_mx_f16_p5)
+PETIT_FAMILY_TABLE(mx_f16, solutions_mx_f16_p1, solutions_mx_f16_p2, solutions_mx_f16_p3, solutions_mx_f16_p4, solutions_mx_f16_p5, solutions_mx_f16_p6)
 #undef PETIT_FAMILY_TABLE
 
 namespace {

@@ -60,7 +60,8 @@ template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int 
     static_assert(DA > 0 || (kDma >= 1 && kDma * WN * 4 == BM), "the waves of a K part split a tile into whole KiB loads");
     static_assert(DA == 0 || (DA <= 4 && (DA > 1 ? (DA - 1) * kDma : 0) <= 63), "the loader's counted vmcnt is a 6-bit field");
     static_assert(KS % D == 0, "ring depth must divide the span");
-    static_assert(!AT::kBfp && !AT::kAdaptive, "plain bf16 / fp16 activations");
+    static_assert(!AT::kBfp, "plain bf16 / fp16 activations, or Fp16Mx (fast body + exact fallback, device_common.hpp) in the loader-wave form");
+    static_assert(!AT::kAdaptive || (FMT == kFmtMx && DA > 0), "Fp16Mx: fp16 activations x MXFP4 weights, loader-wave form only");
     static_assert(kThreads <= 1024 && kSmemU4 * 16 <= 160 * 1024, "workgroup / LDS budget");
 };
 
@@ -259,9 +260,71 @@ __global__ __launch_bounds__(Cfg::kThreads) void gemm_batch_kernel(const void *a
                         srec[nt] = srec_next[nt];
                 }
             };
-            for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
-                span_body(sp, std::false_type{});
-            span_body(sp_end - 1, std::true_type{});
+            if constexpr (AT::kAdaptive) {
+                // Fp16Mx: the fast body while this lane's scale bytes of the span lie in 114..140; the first span that does not switches THIS WAVE, for the
+                // rest of its range, to the fallback -- exact for any e8m0 scale, written for size, not speed (device_common.hpp): one k-tile per trip of a
+                // rolled loop, the W tile and its scale byte loaded on the spot (the ring's tiles in flight are simply dropped), weights to bf16, every fp16
+                // fragment split into hi + lo bf16 in registers, two MFMAs per word.  It keeps the workgroup's protocol: one barrier per step, the loader
+                // wave never notices.
+                auto needs_fallback = [&]() -> bool {
+                    unsigned bad = 0;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        if ((unsigned)nt < valid_nt)
+                            bad = mx_rec_outside_f16<KS>(srec[nt], bad);
+                    return __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+                };
+                unsigned sp = sp_begin;
+                bool fb = needs_fallback();
+                for (; sp + 1 < sp_end && !fb; ++sp) {
+                    span_body(sp, std::false_type{});
+                    fb = needs_fallback();
+                }
+                if (!fb) {
+                    span_body(sp_end - 1, std::true_type{});
+                } else {
+#pragma unroll 1
+                    for (unsigned kt = sp * KS; kt < sp_end * KS; ++kt) {
+                        const unsigned cur = aslot * Cfg::kTileU4;
+                        aslot = aslot + 1 == (unsigned)Cfg::kSlots ? 0u : aslot + 1;
+                        u32x4 wt[NT];
+                        float sc[NT];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            wt[nt] = buf_load16(w_rsrc, w_voff[nt], kt * kTileBytes, kAuxNt);
+                            const unsigned sb = __builtin_amdgcn_raw_buffer_load_b8(s_rsrc, s_voff[nt] + kt % KS, (kt / KS) * 64 * kRecBytes, kAuxDefault);
+                            sc[nt] = __builtin_bit_cast(float, (sb & 0xffu) << 23);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) {
+                                u32x4 hi, lo;
+                                split_f16(fptr[j][cur + mt * 256], hi, lo);
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = mfma16_hilo(unpack_mx(Bf16{}, wt[nt][j], sc[nt]), hi, lo, acc[mt][nt]);
+                            }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                // the join of the two bodies: see mfma_join_settle (device_common.hpp)
+                static_for<0, 2>([&](auto pass) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            mfma_join_pin(acc[mt][nt]);
+                    if constexpr (decltype(pass)::value == 0)
+                        mfma_join_settle();
+                });
+            } else {
+                for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+                    span_body(sp, std::false_type{});
+                span_body(sp_end - 1, std::true_type{});
+            }
         }
     } else if (part_on) {
         const unsigned kt_begin = sp_begin * KS;

@@ -131,7 +131,8 @@ PETIT_DECLARE_PARTS(nv_f16)
 PETIT_DECLARE_PARTS(mx_bf16)
 PETIT_DECLARE_PARTS(mx_f16)
 #undef PETIT_DECLARE_PARTS
-const SolutionEntry *solutions_nv_bf16_p6(int *); // batched decode (gemm_batch.hpp); fp16 x MXFP4 has none yet (its kernels carry an exact fallback body)
+const SolutionEntry *solutions_nv_bf16_p6(int *); // batched decode (gemm_batch.hpp); fp16 x MXFP4: the loader-wave form only (fast body + exact fallback)
+const SolutionEntry *solutions_mx_f16_p6(int *);
 const SolutionEntry *solutions_nv_f16_p6(int *);
 const SolutionEntry *solutions_mx_bf16_p6(int *);
 const SolutionEntry *solutions_mx_bf16_p5(int *); // native FP4 MFMA kernels: MXFP4 weights only

@@ -418,7 +418,7 @@ BATCH_PROBLEMS = [(33, 272, 4096), (64, 96, 8192), (100, 160, 3072), (128, 64, 2
 
 
 @pytest.mark.parametrize("m,n,k", BATCH_PROBLEMS)
-@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True)])
+@pytest.mark.parametrize("kind,is_bf16", [("nv", True), ("nv", False), ("mx", True), ("mx", False)])
 def test_batch_kernels_every_shape_and_split(pk, kind, is_bf16, m, n, k):
     """csrc/gemm_batch.hpp (17 <= M <= 128, round 5): every instance x cross-workgroup K split 1 / 2 / 4 on problems that exercise what is new in
     it -- several m-blocks with a ragged last one, K ranges that do not divide over the WK parts x the slices (parts that idle through their
@@ -433,7 +433,8 @@ def test_batch_kernels_every_shape_and_split(pk, kind, is_bf16, m, n, k):
     h.a_type = h.c_type = torch.bfloat16 if is_bf16 else torch.float16
     h.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
     batch = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF == 0 and (sid >> 36) & 0xF == 2]
-    assert len(batch) >= 4 and any((sid >> 21) & 7 for sid in batch) and any((sid >> 21) & 7 == 0 for sid in batch), "both forms (with / without a loader wave)"
+    assert len(batch) >= 2 and any((sid >> 21) & 7 for sid in batch), "the loader-wave form"
+    assert any((sid >> 21) & 7 == 0 for sid in batch) or (kind == "mx" and not is_bf16), "the form without a loader wave (fp16 x MXFP4 has the loader-wave form only)"
     ran = 0
     for sid in batch:
         for splitk in (1, 2, 4):
