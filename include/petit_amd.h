@@ -299,7 +299,7 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
  * 2^(E - 24), E = floor(log2(largest |operand|)); their sum is then exact (the same for FP8 / FP6 / FP4 activations and both shapes; a term in
  * another block of the same instruction survives beside +-big of any size).  With P_b the largest |a w| of block b, T the sum over blocks of
  * |block sum| (no accumulation order or K split has a larger partial sum) and gs the global scale, every output satisfies
- *     |c - exact| <= gs * ( 33 * sum_b 2^(floor(log2(max(P_b, T))) - 24) + 16 * 2^-24 * T )  +  one 16-bit rounding,
+ *     |c - exact| <= gs * 2^-24 * ( 33 * sum_b max(P_b, T) + 16 * T )  +  one 16-bit rounding            (2^floor(log2 x) <= x),
  * about 1e-4 of sum |a w| at K = 8192 in the worst case, far below 1 % of the result unless the terms cancel to < 1 % of their size.  The tests
  * (tests/test_gpu_parity.py native_exact_bound) and tools/fuzz_parity.py hold every native kernel to it.
  */

@@ -1216,24 +1216,23 @@ def native_exact_bound(a_q: np.ndarray, w: np.ndarray, gs: float) -> np.ndarray:
     So a 32-element block contributes at most (32 + 1) * 2^(E_b - 24), E_b = floor(log2(max(largest |product| of the block, |running sum|))).  The
     running sum of ANY accumulation order or K split is at most T = sum over blocks of |block sum|; the largest product of a block is at most
     max|a| * max|w| over the block; the cross-wave / cross-slice f32 additions (K parts, K groups, split-K slabs: <= 16 of them) add 2^-24 T each.
-        bound = gs * ( 33 * sum_b 2^(floor(log2(max(amax_b * wmax_b, T))) - 24)  +  16 * 2^-24 * T )
+        bound = gs * 2^-24 * ( 33 * sum_b max(amax_b * wmax_b, T)  +  16 * T )          (2^floor(log2 x) <= x)
     a_q [m, K] (the quantised activations, dequantised), w [n, K] (dequantised weights without the global scale) -> [m, n]."""
     m, k = a_q.shape
     n = w.shape[0]
     nb = k // 32
-    A = a_q.astype(np.float64).reshape(m, nb, 32)
-    W = w.astype(np.float64).reshape(n, nb, 32)
-    amax = np.abs(A).max(axis=2)
+    A = np.ascontiguousarray(a_q.astype(np.float32).reshape(m, nb, 32).transpose(1, 0, 2))        # [nb, m, 32]
+    W = w.astype(np.float32).reshape(n, nb, 32)
+    amax = np.abs(A).max(axis=2)                                                                   # [nb, m]
     out = np.empty((m, n))
-    step = max(1, (8 << 20) // max(1, m * nb))                 # column chunks: [m, chunk, nb] stays under ~64 MB
+    step = max(1, (16 << 20) // max(1, m * nb))                # column chunks: [nb, m, chunk] stays under ~64 MB of f32
     for c0 in range(0, n, step):
-        Wc = W[c0:c0 + step]
-        bs = np.einsum("mbi,nbi->mnb", A, Wc, optimize=True)
-        T = np.abs(bs).sum(axis=2)
-        pmax = amax[:, None, :] * np.abs(Wc).max(axis=2)[None, :, :]
-        mx = np.maximum(np.maximum(pmax, T[:, :, None]), 1e-300)
-        unit = np.exp2(np.floor(np.log2(mx)) - 24.0)
-        out[:, c0:c0 + step] = 33.0 * unit.sum(axis=2) + 16.0 * 2.0 ** -24 * T
+        Wc = np.ascontiguousarray(W[c0:c0 + step].transpose(1, 2, 0))                              # [nb, 32, chunk]
+        bs = np.matmul(A, Wc)                                   # block sums [nb, m, chunk] (f32: only their magnitude enters the bound; x 1.001 below)
+        T = np.abs(bs).sum(axis=0, dtype=np.float64) * 1.001
+        pmax = amax[:, :, None] * np.abs(Wc).max(axis=1)[:, None, :]
+        mx = np.maximum(pmax, T[None, :, :].astype(np.float32))          # (2^floor(log2 x) <= x: the truncation unit of a block is at most max(P_b, T) 2^-24)
+        out[:, c0:c0 + step] = 2.0 ** -24 * (33.0 * mx.sum(axis=0, dtype=np.float64) + 16.0 * T)
     return abs(gs) * out
 
 
