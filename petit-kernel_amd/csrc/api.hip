@@ -539,6 +539,45 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
                         (act && !act_runs(*c.entry, c.splitk, restrict_)) || !entry_allows(*c.entry, restrict_)))
             c.entry = nullptr;
     }
+    if (c.entry && klass == kClassExact && m > 512 && c.splitk == 1 && !act) {
+        // Prefill at a ragged M.  The bucket's row was measured at ONE M (1024 / 2048 / 8192: whole multiples of every tile height), where its grid fills
+        // the chip in whole rounds; at M = 2084 a 128 x 256 tile on N = 8192 needs 544 workgroups = 2.1 rounds of 256 and pays for three (measured: `o`
+        // 846 TFLOP/s at M = 2084 between 1071 at 1024 and 982 at 4314).  The shape's rows of the other prefill buckets are measured kernels of this very
+        // shape with other tile sizes.  `waste` = (rounds the grid takes x workgroup slots) / workgroups, rounds counted as the fitted cost model counts them
+        // (half way between fractional and whole): when the row's kernel wastes > 8 % more here than at the M it was measured at, the sibling row that
+        // wastes the least takes over if that is > 8 % less than the row's own.  Never at the measured M itself: a measurement beats this estimate.
+        TunedEntry alt[24];
+        const int n_alt = tuned_shape_rows(dev, a_type, b_type, n, k, klass, alt, 24);
+        const int num_cus = arch_info(dev).num_cus;
+        auto waste = [&](const SolutionEntry &e, unsigned mm) {
+            unsigned bm, bn;
+            entry_tile(e, &bm, &bn);
+            const StepCost *sc = step_cost(e);
+            const double slots = num_cus * (sc ? (double)sc->resident : 1.0);
+            const double tiles = (double)((mm + bm - 1) / bm) * (double)((n + bn - 1) / bn), r = tiles / slots;
+            const double rounds = r <= 1.0 ? 1.0 : 0.5 * (r + (double)(unsigned long)(r + 0.999999));
+            return rounds * slots * bm * bn / ((double)mm * n); // (work paid for / work asked for: ragged edges count too)
+        };
+        unsigned lo = 0, hi = 0;
+        for (int i = 0; i < n_alt; ++i)
+            if (alt[i].solution == tuned && m >= alt[i].m_lo && m <= alt[i].m_hi)
+                lo = alt[i].m_lo, hi = alt[i].m_hi;
+        const unsigned rep = hi == 0 ? m : hi > 4096 ? 8192u : hi == 4096 ? 2048u : hi; // the M the row was measured at (tools/make_tuned_inc.py BUCKET)
+        const double own = waste(*c.entry, m);
+        if (own > 1.08 * waste(*c.entry, rep)) {
+            double best_w = own;
+            for (int i = 0; i < n_alt; ++i) {
+                if (alt[i].m_hi <= 512 || solution_splitk(alt[i].solution) != 1)
+                    continue;
+                const SolutionEntry *e = find_entry(fam, alt[i].solution);
+                if (!e || !entry_fits(*e, m, k) || is_batch(*e))
+                    continue;
+                const double w = waste(*e, m);
+                if (w < 0.92 * own && w < best_w)
+                    best_w = w, c.entry = e;
+            }
+        }
+    }
     if (!c.entry && !nearest_disabled()) {
         // no row for this shape: the rows of the nearest tabulated shapes (hal.h tuned_nearest_list) whose kernels can run this problem.  The
         // nearest one wins unless the fitted cost model (tiled_cost_us: the large-M kernels, 6-9 % median error) can price BOTH it and a farther
@@ -697,7 +736,11 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         // (measured: down 8192 x 28672 at M = 16, staged 16 x 64 tiles with a K split of 2: 29.0 us against 30.5 unsplit -- every CU
         // then pulls half of the activations)
         const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1) || is_batch(e);
-        if (is_batch(e) && (m > 256 || m > 8u * 16u * (unsigned)s.mt))
+        static const unsigned batch_max_m = [] { // $PETIT_AMD_BATCH_MAX_M: experiments with the batched-decode kernels beyond their regime
+            const char *v = getenv("PETIT_AMD_BATCH_MAX_M");
+            return v && *v ? (unsigned)strtoul(v, nullptr, 10) : 256u;
+        }();
+        if (is_batch(e) && (m > batch_max_m || m > 8u * 16u * (unsigned)s.mt))
             continue; // (16-128-row workgroups that each stream their whole column block: never a candidate for prefill, or beyond eight m-blocks)
         if (!splittable)
             continue;

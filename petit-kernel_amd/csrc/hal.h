@@ -61,6 +61,9 @@ struct TunedNeighbour {
     double distance;
 };
 int tuned_nearest_list(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, TunedNeighbour *out, int cap);
+// Every built-in / run-time row of ONE tabulated shape and class (all M buckets), for callers that want to weigh a bucket's row against its neighbours'
+// (api.hip choose_auto: tile quantisation at a ragged prefill M).  Returns the count written (<= cap).
+int tuned_shape_rows(int device, int a_type, int b_type, unsigned n, unsigned k, int klass, TunedEntry *out, int cap);
 // class of a solution id: 0 exact, 8 / 4 native with MXFP8 / MXFP4 activations
 int solution_class(uint64_t solution);
 // Add (or replace) a row at run time; thread safe; bumps tuned_generation() so cached default picks are re-derived.

@@ -285,6 +285,25 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
     return 0;
 }
 
+int tuned_shape_rows(int device, int a_type, int b_type, unsigned n, unsigned k, int klass, TunedEntry *out, int cap) {
+    if (!tuned_lookup_enabled(device) || cap <= 0)
+        return 0;
+    b_type = canonical_b_type(b_type);
+    int count = 0;
+    std::call_once(g_override_once, load_override);
+    if (g_override_count.load(std::memory_order_acquire)) {
+        std::lock_guard<std::mutex> lock(g_rows_mutex);
+        for (const TunedEntry &e : g_override)
+            if (e.a_type == a_type && e.b_type == b_type && e.n == n && e.k == k && solution_class(e.solution) == klass && count < cap)
+                out[count++] = e;
+    }
+    if (const ShapeRun *run = builtin_index(klass).find(a_type, b_type, n, k))
+        for (const TunedEntry *e = run->first; e != run->last && count < cap; ++e)
+            if (e->a_type == a_type && e->b_type == b_type && e->n == n && e->k == k && solution_class(e->solution) == klass)
+                out[count++] = *e;
+    return count;
+}
+
 int tuned_nearest_list(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, TunedNeighbour *out, int cap) {
     if (!tuned_lookup_enabled(device) || n == 0 || k == 0 || cap <= 0)
         return 0;

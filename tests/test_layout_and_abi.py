@@ -298,13 +298,21 @@ def test_arch_table_rows_and_tune_file_override(tmp_path):
     rows = re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}",
                       (ROOT / "petit-kernel_amd/csrc/tuned_gfx950.inc").read_text())
     assert len(rows) >= 100
+    prefill_kernels = {}
+    for at, bt, n, k, lo, hi, sol in rows:
+        if int(hi) > 512:
+            prefill_kernels.setdefault((int(at), int(bt), int(n), int(k)), set()).add((int(sol, 16) & ~(0xF << 60)) | (1 << 60))
     for at, bt, n, k, lo, hi, sol in rows:
         at, bt, n, k, lo, hi, sol = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16)
         hints = _lib.SolutionHints(at, bt, at, 0)
         assert (sol >> 48) & 0xF not in (9, 13), "a native-FP4 kernel must never be a default"   # (as tools/make_tuned_inc.py)
         assert _lib.lib.petit_gemm_default_solution(C.byref(hints), row_rep_m(lo, hi), n, k) == sol, (at, bt, n, k, lo, hi, hex(sol))
         for m in {lo, min(hi, lo + 3)}:
-            assert same_kernel_split_at_most(_lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k), sol), (at, bt, n, k, m, hex(sol))
+            got = _lib.lib.petit_gemm_default_solution(C.byref(hints), m, n, k)
+            if hi <= 512:
+                assert same_kernel_split_at_most(got, sol), (at, bt, n, k, m, hex(sol))
+            else:   # prefill: at a ragged M a sibling row's kernel may take over when its grid quantises > 8 % better (csrc/api.hip choose_auto)
+                assert same_kernel_split_at_most(got, sol) or got in prefill_kernels[(at, bt, n, k)], (at, bt, n, k, m, hex(sol), hex(got))
             assert "unknown" not in _lib.describe_solution(sol)
     # override: pick some other enumerated kernel for one of the table's shapes
     at, bt, n, k, lo, hi, sol = rows[0]

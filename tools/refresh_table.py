@@ -3,7 +3,7 @@
 
 For every (family, shape, M bucket): time what `solution_id = -1` runs today (tools/benchlib.py: graph replay, rotating weights), ask the in-library tuner
 (petit_kernel.tune_tensors, persist = False: ~0.1 s per problem instead of the exhaustive sweep's ~20 s) for its pick, time that the same way, time the default
-again; where the tuner's pick beats BOTH default timings by more than --gain (default 3 %), write a row in the $PETIT_AMD_TUNE_FILE format for
+again; where the tuner's pick beats BOTH default timings by more than --gain (default 5 %; 3 % when the same challenger won an earlier session too: --confirm), write a row in the $PETIT_AMD_TUNE_FILE format for
 tools/make_tuned_inc.py.  Rows of rounds that predate newer kernel families go stale silently; this finds them in minutes."""
 import argparse
 import json
@@ -28,12 +28,20 @@ def main():
     ap.add_argument("--shapes", default=ALL)
     ap.add_argument("--ms", default="1,2,4,8,16,32,64,128,256,512")
     ap.add_argument("--families", default="nv:bf16,nv:f16,mx:bf16,mx:f16")
-    ap.add_argument("--gain", type=float, default=0.03)
+    ap.add_argument("--gain", type=float, default=0.05, help="a challenger seen in THIS session only must beat both default timings by this much")
+    ap.add_argument("--confirm", default="", help="the .json log of an EARLIER refresh session: a challenger that also won there (same id, >= --confirm-gain in both "
+                                                    "sessions) is adopted at the lower margin -- single-session timings sit inside the noise the picks are made on")
+    ap.add_argument("--confirm-gain", type=float, default=0.03)
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "refresh.tune.txt"))
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(dev)
     rows, log = [], []
+    earlier = {}
+    if args.confirm:
+        for r in json.loads(Path(args.confirm).read_text())["log"]:
+            if "tuned_us" in r and r["tuned_us"] < (1.0 - args.confirm_gain) * min(r["default_us"], r.get("default_us_again", r["default_us"])):
+                earlier[(r["family"], r["n"], r["k"], r["m"])] = r["tuned"]
     t0 = time.time()
     for fam in args.families.split(","):
         fmt, dt = fam.split(":")
@@ -52,7 +60,9 @@ def main():
                     t_t = g.time(tuned, stream, reps=5)["us"]
                     t_d2 = g.time(dflt, stream, reps=5)["us"]
                     rec.update(tuned_us=t_t, default_us_again=t_d2)
-                    if t_t < (1.0 - args.gain) * min(t_d1, t_d2):
+                    confirmed = earlier.get((fam, n, k, m)) == f"0x{tuned:x}" and t_t < (1.0 - args.confirm_gain) * min(t_d1, t_d2)
+                    rec["confirmed_by_earlier_session"] = confirmed
+                    if confirmed or t_t < (1.0 - args.gain) * min(t_d1, t_d2):
                         rows.append((g.a_type, g.b_type, n, k, m, tuned))
                         rec["replaced"] = True
                         print(f"{fam} {name} M={m}: {min(t_d1, t_d2):.2f} -> {t_t:.2f} us  {_lib.describe_solution(tuned)}", flush=True)
