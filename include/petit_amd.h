@@ -294,14 +294,18 @@ uint64_t petit_workspace_bytes(uint64_t solution_id, unsigned m, unsigned n);
  * registered workspace of petit_native_workspace_bytes(m, k) bytes for the quantised activations.
  *
  * Exactness of the class, given the quantised activations (derived from the instruction, not fitted: tools/probes/mfma_scale_align.hip,
- * profiles/r05_mfma_scale_align.txt).  Inside v_mfma_scale_f32_{32x32x64,16x16x128}_f8f6f4 the products of one pass -- never more than one
- * 32-element block -- and the incoming accumulator are aligned to the largest of them, and every operand is TRUNCATED to a multiple of
- * 2^(E - 24), E = floor(log2(largest |operand|)); their sum is then exact (the same for FP8 / FP6 / FP4 activations and both shapes; a term in
- * another block of the same instruction survives beside +-big of any size).  With P_b the largest |a w| of block b, T the sum over blocks of
- * |block sum| (no accumulation order or K split has a larger partial sum) and gs the global scale, every output satisfies
- *     |c - exact| <= gs * 2^-24 * ( 33 * sum_b max(P_b, T) + 16 * T )  +  one 16-bit rounding            (2^floor(log2 x) <= x),
- * about 1e-4 of sum |a w| at K = 8192 in the worst case, far below 1 % of the result unless the terms cancel to < 1 % of their size.  The tests
- * (tests/test_gpu_parity.py native_exact_bound) and tools/fuzz_parity.py hold every native kernel to it.
+ * profiles/r05_mfma_scale_align.txt; the same for v_mfma_scale_f32_32x32x64 and 16x16x128).
+ *  (1) every activation format: the partial sums of one 32-element block and the incoming accumulator are aligned to the largest of them and each
+ *      is TRUNCATED to a multiple of 2^(E - 24), E = floor(log2(largest)); the sum of the aligned values is exact.  A term in another block of the
+ *      same instruction survives beside +-big of any size; with FP6 / FP4 activations a block's own sum is exact.
+ *  (2) FP8 (e4m3) activations only: inside a block the products are first summed in groups of 8 consecutive k, aligned to the group's largest
+ *      product and truncated 14 bits below it (unit 2^(e_a + e_w - 13)).
+ * With P_b / P_g the largest |a w| of block b / group g, T the sum over blocks of |block sum| (no accumulation order or K split has a larger partial
+ * sum) and gs the global scale, every output satisfies
+ *     |c - exact| <= gs * [ 2^-24 * (33 * sum_b max(P_b, T) + 16 * T)  +  (FP8 activations) 7 * 2^-13 * sum_g P_g ]  +  one 16-bit rounding:
+ * a worst case (every truncation a full unit, all in one direction) of ~1e-4 of sum |a w| for FP6 / FP4 activations and ~5e-4 for FP8 at K = 8192;
+ * typical errors are one 16-bit rounding of the result.  The tests (tests/test_gpu_parity.py native_exact_bound) and tools/fuzz_parity.py hold every
+ * native kernel to it; rounds 3-4 used an empirical 1e-5 ... 4e-5 of sum |a w|, which a longer fuzz run always exceeded somewhere.
  */
 int petit_enable_native_fp4(int enable);
 uint64_t petit_native_workspace_bytes(unsigned m, unsigned k);

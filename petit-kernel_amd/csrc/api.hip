@@ -728,7 +728,7 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         have_ref |= is_ref;
         // prefill: the streaming kernels re-read W once per 16-64 rows -- tens of milliseconds per launch at M = 8192, never a winner above
         // M = 512 (0 of the 1104 measured rows there) -- so only the one that serves as the reference output is run
-        if (!is_ref && m > 512 && s.am >= 0)
+        if (!is_ref && m > 512 && s.am >= 0 && !is_batch(e))
             continue;
         push(e, 1, is_ref);
         // K splits: the large-M kernels and the streaming kernels (direct and staged) take any split; the decode / shared-tile
@@ -738,10 +738,10 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1) || is_batch(e);
         static const unsigned batch_max_m = [] { // $PETIT_AMD_BATCH_MAX_M: experiments with the batched-decode kernels beyond their regime
             const char *v = getenv("PETIT_AMD_BATCH_MAX_M");
-            return v && *v ? (unsigned)strtoul(v, nullptr, 10) : 256u;
+            return v && *v ? (unsigned)strtoul(v, nullptr, 10) : 1024u; // (measured: the 128 x 128 form wins `o` / `down` at M = 512 by 3-10 %: profiles/r05_summary.md)
         }();
         if (is_batch(e) && (m > batch_max_m || m > 8u * 16u * (unsigned)s.mt))
-            continue; // (16-128-row workgroups that each stream their whole column block: never a candidate for prefill, or beyond eight m-blocks)
+            continue; // (16-128-row workgroups that each stream their whole column block: not beyond M = 1024 / eight m-blocks)
         if (!splittable)
             continue;
         for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)

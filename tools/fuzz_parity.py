@@ -94,7 +94,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
                 got = T.to_f32(T.bits(c), is_bf16).astype(np.float64)
                 fin = np.isfinite(exact) & (np.abs(exact) < (3e38 if is_bf16 else 6e4))
                 err = np.abs(got - exact)[fin]
-                bound = np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), T.native_exact_bound(a_q, dq, gs))[fin]   # (as the tests: derived from the instruction)
+                bound = np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), T.native_exact_bound(a_q, dq, gs, fmt))[fin]   # (as the tests: derived from the instruction)
                 assert (err <= bound).all(), (f"native {fmt}: {int((err > bound).sum())} of {err.size} elements over the bound, worst margin err / bound = {(err / bound).max():.2f} "
                                               f"(there: |exact| = {np.abs(exact)[fin][np.argmax(err / bound)]:.3g}, sum|a||w| = {sum_abs[fin][np.argmax(err / bound)]:.3g})")
         n_ok += 1

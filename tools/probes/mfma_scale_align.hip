@@ -198,6 +198,106 @@ int main() {
                     if (bits <= 0 && (int)gap < sum_same.lost_from) sum_same.lost_from = (int)gap;
                 }
             }
+            // ---- same block, the widest gap the formats allow: weights 6 on the big pair and 0.5 on the small term; the pair adjacent (k = 0, 1) and far apart (k = 0, 31)
+            for (int e = 0; e < 16; ++e) {
+                const float small = ldexpf(full, -e);
+                bool ok = false;
+                const int n = fmt == 0 ? 256 : fmt == 2 ? 64 : 16;
+                for (int c = 0; c < n; ++c)
+                    if ((fmt == 0 ? dec_fp8(c) : fmt == 2 ? dec_fp6(c) : dec_fp4(c)) == small && !(fmt == 0 && (c & 127) == 127))
+                        ok = true;
+                if (!ok)
+                    continue;
+                for (int far = 0; far < 2; ++far) {
+                    Operands o;
+                    term(o, shape, fmt, 0, big, 6.0f), term(o, shape, fmt, far ? 31 : 1, -big, 6.0f), term(o, shape, fmt, 16, small, 0.5f);
+                    const float got = R.run(o, shape, fmt);
+                    const double exact = 0.5 * small, gap = log2(6.0 * big / exact);
+                    printf("%dx%d %s same6(%s) %.2f %g %g 0 %.9g %.9g %.1f\n", shape, shape, fname[fmt], far ? "pair k=0,31" : "pair k=0,1", gap, 6.0 * big, exact, got, exact,
+                           surviving_bits(got, exact, exact));
+                }
+            }
+            // ---- pair sums without cancellation: 6 * big at k = 0 plus 0.5 * small at k = d.  The exact sum needs (gap + 4) bits: how many does the instruction keep,
+            //      and does it depend on how far apart the two k are (i.e. on which terms are added first)?
+            for (int d : {1, 2, 3, 4, 5, 8, 15, 16, 17, 31}) {
+                int kept_min = 99;
+                for (int e = 0; e < 16; ++e) {
+                    const float small = ldexpf(full, -e);
+                    bool ok = false;
+                    const int n = fmt == 0 ? 256 : fmt == 2 ? 64 : 16;
+                    for (int c = 0; c < n; ++c)
+                        if ((fmt == 0 ? dec_fp8(c) : fmt == 2 ? dec_fp6(c) : dec_fp4(c)) == small && !(fmt == 0 && (c & 127) == 127))
+                            ok = true;
+                    if (!ok)
+                        continue;
+                    Operands o;
+                    term(o, shape, fmt, 0, big, 6.0f), term(o, shape, fmt, d, small, 0.5f);
+                    const float got = R.run(o, shape, fmt);
+                    const double exact = 6.0 * big + 0.5 * small;
+                    const double err = fabs((double)got - exact);
+                    // bits of the sum kept below its leading bit: 24 = an exactly rounded f32
+                    const int kept = err == 0.0 ? 24 : (int)floor(log2(fabs(exact)) - log2(err));
+                    if (kept < kept_min) kept_min = kept;
+                    printf("%dx%d %s pairsum(d=%d) gap %.2f exact %.9g got %.9g bits_kept %d\n", shape, shape, fname[fmt], d, log2(6.0 * big / (0.5 * small)), exact, (double)got, kept);
+                }
+                printf("PAIRSUM %dx%d %s d=%d: fewest significant bits of big + small kept = %d\n", shape, shape, fname[fmt], d, kept_min);
+            }
+            // ---- random blocks: the error of ONE instruction against the exact sum, in units of 2^(E - 24), E = floor(log2(largest |term|)), terms = the products and C.
+            //      (i) one block non-zero; (ii) every block non-zero, block scales within +-S binades; C random of the size of the sum or zero
+            {
+                unsigned long long rng = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(shape * 131 + fmt);
+                auto next = [&]() { rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17; return rng; };
+                const int ncodes = fmt == 0 ? 256 : fmt == 2 ? 64 : 16, K = shape == 32 ? 64 : 128;
+                for (int mode = 0; mode < 4; ++mode) { // 0: one block, C = 0; 1: one block, C random; 2: all blocks scales +-4, C random; 3: all blocks scales +-12, C random
+                    double worst = 0.0, worst_rel = 0.0;
+                    for (int trial = 0; trial < 1500; ++trial) {
+                        Operands o;
+                        double exact = 0.0, maxterm = 0.0, sumabs = 0.0;
+                        const int nblk_used = mode < 2 ? 1 : nblk;
+                        for (int b = 0; b < nblk_used; ++b) {
+                            const int sb = mode == 2 ? (int)(next() % 9) - 4 : mode == 3 ? (int)(next() % 25) - 12 : 0;
+                            o.sb[lane_of_block(shape, b)] = 127 + sb;
+                            for (int i = 0; i < 32; ++i) {
+                                int code;
+                                do
+                                    code = (int)(next() % ncodes);
+                                while (fmt == 0 && (code & 127) == 127);
+                                const float act = fmt == 0 ? dec_fp8(code) : fmt == 2 ? dec_fp6(code) : dec_fp4(code);
+                                const float wgt = dec_fp4((int)(next() % 16));
+                                int lane, elem;
+                                locate(shape, 4, 32 * b + i, &lane, &elem);
+                                put(o.a, lane, elem, 4, enc(4, wgt == 0.f ? 0.f : wgt));
+                                locate(shape, fmt, 32 * b + i, &lane, &elem);
+                                put(o.b, lane, elem, bits_of(fmt), code);
+                                const double p = (double)act * wgt * ldexp(1.0, sb);
+                                exact += p, sumabs += fabs(p);
+                                if (fabs(p) > maxterm) maxterm = fabs(p);
+                            }
+                        }
+                        (void)K;
+                        float cin = 0.f;
+                        if (mode >= 1) {
+                            cin = (float)(((double)(next() % 2000001) / 1000000.0 - 1.0) * (sumabs / 8.0 + 1e-3));
+                            o.c[0] = cin;
+                            exact += cin;
+                            if (fabs((double)cin) > maxterm) maxterm = fabs((double)cin);
+                        }
+                        if (maxterm == 0.0)
+                            continue;
+                        const float got = R.run(o, shape, fmt);
+                        const double unit = ldexp(1.0, (int)floor(log2(maxterm)) - 24);
+                        const double err = fabs((double)got - exact);
+                        // (the final f32 rounding of the result itself is not the instruction's internal error: subtract half an ulp of the result)
+                        const double res_ulp = exact == 0.0 ? 0.0 : ldexp(1.0, (int)floor(log2(fabs(exact))) - 23);
+                        const double internal = err > res_ulp ? err - res_ulp : 0.0;
+                        if (internal / unit > worst) worst = internal / unit;
+                        if (err / sumabs > worst_rel) worst_rel = err / sumabs;
+                    }
+                    printf("RANDOM %dx%d %s mode %d (%s): worst internal error = %.2f units of 2^(E-24); worst |err| / sum|terms| = %.3g\n", shape, shape, fname[fmt], mode,
+                           mode == 0 ? "one block, C = 0" : mode == 1 ? "one block, C random" : mode == 2 ? "all blocks, scales +-4 binades, C random" : "all blocks, scales +-12 binades, C random",
+                           worst, worst_rel);
+                }
+            }
             // ---- cross block: big pair in block 0 (scale 2^G), small in block b (scale 1)
             for (int b = 1; b < nblk; ++b)
                 for (int G = 0; G <= 64; ++G) {
