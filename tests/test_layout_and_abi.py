@@ -461,7 +461,7 @@ def test_unseen_shapes_stay_close_to_the_measured_best():
         return tuple(float(x) for x in m.groups()), buckets, out
     (median, p90, _), buckets, out = run("--heldout", "--by-m", "--mode", "nearest")
     assert len(buckets) == 13 and median <= 1.02 and p90 <= 1.16 and all(b[0] <= 1.06 for b in buckets), out
-    assert all(b[1] <= 1.35 for b in buckets), out                     # the tail: p90 of every bucket
+    assert all(b[1] <= 1.40 for b in buckets), out                     # the tail: p90 of every bucket (measured 1.05-1.35)
     (median, p90, _), buckets, out = run("--by-m", "--data", str(ROOT / "profiles" / "r04_table_candidates.csv.gz"))
     assert len(buckets) == 10 and median <= 1.04 and p90 <= 1.25 and all(b[0] <= 1.06 for b in buckets), out
 

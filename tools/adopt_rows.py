@@ -45,10 +45,15 @@ def main():
         if key in c1 and c1[key].get(old[0]) is not None:
             o1 = c1[key][old[0]]
             gm, cand = min((math.sqrt(c1[key][s] * c2[key][s]), s) for s in c2[key] if s in c1[key])
-            if c1[key][cand] < 0.97 * o1 and c2[key][cand] < 0.97 * o2:
+            win, us = b2[key]
+            if c1[key][cand] < 0.97 * o1 and c2[key][cand] < 0.97 * o2 and not (win not in c1[key] and us < 0.95 * c2[key][cand]):
                 out.append((at, bt, n, k, m, cand))
                 gains.append(math.sqrt(o1 * o2) / gm)
                 two += 1
+            elif win not in c1[key] and us < 0.95 * o2:   # a kernel the earlier session did not have: the single-session margin
+                out.append((at, bt, n, k, m, win))
+                gains.append(o2 / us)
+                one += 1
             else:
                 kept += 1
         else:
