@@ -506,14 +506,42 @@ int nearest_k() {
     }();
     return v;
 }
-// a farther neighbour's kernel replaces a nearer one's only when the cost model puts it this far ahead (the model's own error is 6-9 % per kernel; 0.85 from a sweep over the held-out shapes, profiles/r05_heuristic.md)
+// a farther neighbour's kernel replaces a nearer one's only when its grid overhead on THIS problem (relative to the overhead it won with at home) is
+// this much smaller (0.87 = 1 / 1.15 from a sweep over the held-out shapes, profiles/r05_heuristic.md)
 double nearest_switch_gain() { // $PETIT_AMD_NEAREST_GAIN overrides (tools/check_heuristic.py sweeps it)
     static const double v = [] {
         const char *e = getenv("PETIT_AMD_NEAREST_GAIN");
         const double x = e && *e ? strtod(e, nullptr) : 0.0;
-        return x > 0.0 && x <= 1.0 ? x : 0.85;
+        return x > 0.0 && x <= 1.0 ? x : 0.87;
     }();
     return v;
+}
+// What a (kernel, K split) pays on a problem for not fitting it: the last round of workgroups that fills only part of the chip, the K slices
+// that come out uneven, the columns of the last n-tile beyond N.  1.0 = a perfect fit; 0 = a kernel kind this does not describe (the decode /
+// streaming kernels: their grids are not tile grids).  A grid below one round is NOT a misfit (the shape is small, whatever the kernel).
+// A table row's kernel won at ITS shape with whatever overhead it has there; overhead(new) / overhead(home) says how well that win transfers.
+double grid_overhead(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k, int num_cus) {
+    const StreamShape &s = e.shape;
+    const bool tiled = s.am == kTiledAm, wide = s.am == kWideAm && !is_shared(e), batch = is_batch(e);
+    if (!tiled && !wide && !batch)
+        return 0.0;
+    unsigned bm, bn;
+    entry_tile(e, &bm, &bn);
+    const unsigned kp = batch ? (unsigned)s.wk : (wide && s.wm == 3) ? 2u : 1u; // K parts inside the workgroup
+    const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
+    if (nspans == 0 || bm == 0 || bn == 0)
+        return 0.0;
+    const unsigned sk = std::max(1u, std::min(splitk, nspans >= kp ? nspans / kp : 1u)); // (the launchers drop empty slices)
+    const unsigned parts = std::min(sk * kp, nspans);
+    const StepCost *c = step_cost(e);
+    const double resident = c ? (double)c->resident : 1.0;
+    const double ntiles = (double)((n + bn - 1) / bn);
+    const double r = (double)((m + bm - 1) / bm) * ntiles * sk / (num_cus * resident);
+    const double rounds = r <= 1.0 ? 1.0 : 0.5 * (r + std::ceil(r - 1e-9)); // (as tiled_cost_us: dispatch is dynamic)
+    const double q = rounds / std::max(r, 1.0);
+    const double kq = (double)((nspans + parts - 1) / parts) * parts / nspans;
+    const double waste = r >= 1.0 ? ntiles * bn / n : 1.0;
+    return q * kq * waste;
 }
 AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool act, unsigned m, unsigned n, unsigned k,
                        int klass = kClassExact, unsigned restrict_ = 0) {
@@ -579,34 +607,49 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
         }
     }
     if (!c.entry && !nearest_disabled()) {
-        // no row for this shape: the rows of the nearest tabulated shapes (hal.h tuned_nearest_list) whose kernels can run this problem.  The
-        // nearest one wins unless the fitted cost model (tiled_cost_us: the large-M kernels, 6-9 % median error) can price BOTH it and a farther
-        // neighbour's kernel on THIS problem's grid and the farther one comes out clearly ahead -- a neighbour's winner was chosen for how ITS N
-        // and M fill the chip in whole rounds, which does not transfer (held-out shapes, profiles/r05_heuristic.md).
+        // no row for this shape: the rows of the nearest tabulated shapes (hal.h tuned_nearest_list) whose kernels can run this problem.  A
+        // neighbour's winner was chosen for how ITS N, K and M fill the chip in whole rounds, which does not transfer (held-out shapes,
+        // profiles/r05_heuristic.md: the nearest row taken blindly reads p90 1.2-1.35 at 17 <= M <= 4096, and the best of three neighbours'
+        // kernels 1.00-1.14).  So each runnable neighbour gets the ratio grid_overhead(this problem) / grid_overhead(its own shape), and the
+        // NEAREST one within 15 % of the best ratio wins: distance still decides between kernels that fit equally well.
         constexpr int kNeighbours = 3;
         TunedNeighbour nb[kNeighbours];
         const int found = tuned_nearest_list(dev, a_type, b_type, m, n, k, klass, kNearestMaxDistance, nb, nearest_k() < kNeighbours ? nearest_k() : kNeighbours);
         const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
         const int num_cus = arch_info(dev).num_cus;
-        double best_us = 0.0;
+        struct Runnable {
+            const SolutionEntry *e;
+            unsigned sk;
+            double ratio; // 0: unknown
+        } run[kNeighbours];
+        int n_run = 0;
         for (int i = 0; i < found; ++i) {
             const SolutionEntry *e = find_entry(fam, nb[i].solution);
-            unsigned sk = solution_splitk(nb[i].solution);
-            if (!e || entry_class(*e) != klass || !entry_fits(*e, m, k) || sk == 0 || sk > nspans || (act && !act_runs(*e, sk, restrict_)) ||
+            const unsigned row_sk = solution_splitk(nb[i].solution);
+            if (!e || entry_class(*e) != klass || !entry_fits(*e, m, k) || row_sk == 0 || row_sk > nspans || (act && !act_runs(*e, row_sk, restrict_)) ||
                 !entry_allows(*e, restrict_))
                 continue;
-            sk = guarded_splitk(*e, sk, m, n, k, num_cus);
+            const unsigned sk = guarded_splitk(*e, row_sk, m, n, k, num_cus);
             if (act && !act_runs(*e, sk, restrict_))
                 continue;
-            const bool priced = klass == kClassExact && (e->shape.am == kTiledAm || e->shape.am == kWideAm) && !is_shared(*e) && step_cost(*e) != nullptr;
-            const double us = priced ? tiled_cost_us(*e, m, n, k, num_cus, sk) : 0.0;
-            if (!c.entry) { // the nearest runnable neighbour
-                c.entry = e, c.splitk = sk, best_us = us;
-                if (!priced || nb[i].distance == 0.0)
-                    break; // nothing to compare with (the streaming / decode kernels have no fitted model), or not a neighbour at all
-            } else if (priced && us < nearest_switch_gain() * best_us) {
-                c.entry = e, c.splitk = sk, best_us = us;
-            }
+            const double here = klass == kClassExact ? grid_overhead(*e, sk, m, n, k, num_cus) : 0.0;
+            const double home = here > 0.0 ? grid_overhead(*e, row_sk, m, nb[i].n, nb[i].k, num_cus) : 0.0;
+            run[n_run++] = Runnable{e, sk, home > 0.0 ? here / home : 0.0};
+            if (n_run == 1 && (run[0].ratio == 0.0 || nb[i].distance == 0.0))
+                break; // nothing to compare (a kernel without a tile grid, the native classes), or not a neighbour at all
+        }
+        if (n_run) {
+            double best_ratio = run[0].ratio;
+            for (int i = 1; i < n_run; ++i)
+                if (run[i].ratio > 0.0 && run[i].ratio < best_ratio)
+                    best_ratio = run[i].ratio;
+            int pick = 0;
+            for (int i = 0; i < n_run; ++i)
+                if (run[i].ratio > 0.0 && run[i].ratio * nearest_switch_gain() <= best_ratio) {
+                    pick = i;
+                    break;
+                }
+            c.entry = run[pick].e, c.splitk = run[pick].sk;
         }
     }
     if (!c.entry)

@@ -329,7 +329,18 @@ __device__ __forceinline__ void tile_of_block(unsigned flags, unsigned &bn, unsi
     const unsigned b = blockIdx.y * nx + blockIdx.x, nwg = nx * ny;
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, idx = b >> 3;
     const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; // bijective for any nwg
-    bn = t / ny, bm = t - bn * ny;
+    // An XCD's tiles are consecutive in t and its 32 CUs run 32 consecutive ones at a time.  Column-major t (m fastest)
+    // makes those 32 tiles one W panel x 32 A panels once M has 32 m-tiles: at M = 16 k every n-tile column re-reads all of
+    // A (gate_up: 224 x 268 MB per call).  Bands of `ph` m-tiles, m fastest inside a band: 32 consecutive tiles are
+    // ph A panels x 32 / ph W panels (launch_flags() picks ph so that both cost the same bytes per k-step).
+    const unsigned ph = (flags >> kFlagBandShift) & 0xffu;
+    if (ph == 0 || ph >= ny) {
+        bn = t / ny, bm = t - bn * ny;
+        return;
+    }
+    const unsigned band = t / (ph * nx), tl = t - band * ph * nx;
+    const unsigned rows = min(ph, ny - band * ph);
+    bn = tl / rows, bm = band * ph + (tl - bn * rows);
 }
 
 // Two waves share a SIMD in the 2-workgroups-per-CU kernels, run the same phases (unpack burst, MFMA burst, barrier) and,

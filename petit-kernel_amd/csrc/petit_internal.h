@@ -56,14 +56,14 @@ struct GemmArgs {
     float *workspace;   // fp32 split-K slabs (may be null when splitk == 1)
     unsigned m, n, k;
     unsigned spans_per_wave; // set by the launcher: ceil(spans / (split_k * WK))
-    unsigned flags;          // large-M kernels: kFlagPrio | kFlagXcdRaster (launch_flags(), stream_tu.inc)
+    unsigned flags;          // large-M kernels: kFlagPrio | kFlagXcdRaster | band << kFlagBandShift (launch_flags(), stream_tu.inc)
     // native-FP4 pipeline (gemm_native32.hpp): activations the CALLER already holds quantised (no quantiser launch), and a
     // SiLU-mul epilogue that emits the NEXT GEMM's quantised activations instead of a 16-bit matrix
     const void *qa;          // pre-quantised activations in the k-tile-major scratch layout of format qa_format, or null
     unsigned qa_format;      // 8 (MXFP8) / 4 (MXFP4) when qa is set
     unsigned out_format;     // 0: c is a 16-bit matrix; 8 / 4: c receives [m][n/2] activations quantised to MXFP8 / MXFP4 (act = 1 only)
 };
-enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u };
+enum : unsigned { kFlagPrio = 1u, kFlagXcdRaster = 2u, kFlagBandShift = 8 }; // bits 8..15: m-tiles per raster band (0 = whole columns)
 
 // A group of GEMMs that share the activation rows, for the grouped kernels (petit_gemm_fp4_fp16_grouped): passed by value as a
 // kernel argument; wg_end[i] = workgroups of members 0..i (prefix sums along grid x).
