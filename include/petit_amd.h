@@ -169,6 +169,14 @@ uint64_t petit_gemm_default_solution(const petit_solution_hints *hints,
  * names for workspace_bytes = 0.  epilogue may be NULL. */
 uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id,
                                      const petit_epilogue *epilogue, uint64_t workspace_bytes);
+/* Rows are independent, so a default-pick call (PETIT_SOLUTION_AUTO, exact class) at a prefill M whose tile grid ends a little past a
+ * whole number of rounds of the chip runs as TWO launches on the caller's stream: the first `rows` rows with the kernel picked for them
+ * (a grid of whole rounds), the remaining m - rows rows as a default-pick problem of their own (petit-kernel_amd/csrc/api.hip
+ * plan_row_split; petit_gemm_workspace_bytes covers both).  Returns `rows`, or 0 when the call runs as one launch (always for explicit
+ * ids, the native class, m <= 512, $PETIT_AMD_NO_ROW_SPLIT=1).  petit_gemm_default_solution / _resolve_solution name the kernel of
+ * the problem as a whole; resolve them at (rows) and (m - rows) for the two launches.  No reference counterpart: the reference's
+ * 234-kernel chooser (fp4/algo_chooser.cc:64-132) takes the grid as it comes. */
+unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue);
 
 /*
  * Offline repack of checkpoint tensors into the packed layout the GEMM reads

@@ -679,6 +679,49 @@ int auto_class(uint64_t solution_id) {
 }
 bool is_auto_id(uint64_t solution_id) { return solution_id == PETIT_SOLUTION_AUTO || auto_class(solution_id) != kClassExact; }
 
+// Prefill at a ragged M, second half: a grid a little over a whole number of rounds (M = 2084 on N = 8192 with 128 x 256 tiles: 544 workgroups = 2.125
+// rounds of 256) pays most of a round for its last few tiles.  Rows are independent, so an AUTO call may run as TWO launches on the caller's stream: the
+// bulk -- a whole number of m-tiles whose grid ends (nearly) on a round -- with the kernel picked for it, and the remaining rows as a problem of their own
+// (a few dozen rows are a batched-decode problem: one more pass over W instead of a round of 128-row tiles).  Returns the bulk's rows, 0 = one launch.
+// Estimates, not measurements (times in us): a round costs what the fitted step cost says (else 1 PFLOP/s worth of tiles), rounds are counted as the
+// cost model counts them, the tail costs 8 us + max(W at 4.5 TB/s, its FLOPs at 0.8 PFLOP/s); the split must come out > 5 % ahead (measured where it fires: +6 ... +58 %, profiles/r05_row_split_ab.jsonl).
+// $PETIT_AMD_NO_ROW_SPLIT=1 turns it off (A/B measurements).  Exact class, default pick only: an explicit id runs as named.
+bool row_split_disabled() {
+    static const bool off = [] {
+        const char *e = getenv("PETIT_AMD_NO_ROW_SPLIT");
+        return e && *e && *e != '0';
+    }();
+    return off;
+}
+unsigned plan_row_split(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k, int num_cus) {
+    const StreamShape &s = e.shape;
+    if (row_split_disabled() || m <= 512 || splitk != 1 || !(s.am == kTiledAm || s.am == kWideAm))
+        return 0;
+    unsigned bm, bn;
+    entry_tile(e, &bm, &bn);
+    const StepCost *sc = step_cost(e);
+    const double slots = num_cus * (sc ? (double)sc->resident : 1.0);
+    const unsigned nx = (n + bn - 1) / bn, ny = (m + bm - 1) / bm;
+    const double r = (double)nx * ny / slots;
+    if (r <= 1.0 || ny < 2)
+        return 0;
+    auto rounds = [](double x) { return x <= 1.0 ? 1.0 : 0.5 * (x + std::ceil(x - 1e-9)); };
+    const double t_round = sc ? (k / 128.0) * (double)sc->t1 : 2.0 * bm * bn * (double)k * slots / 1.0e9;
+    const double whole = rounds(r) * t_round;
+    const double w_us = (double)n * k * 0.5625 / 4.5e6;
+    double best = whole;
+    unsigned best_rows = 0;
+    const unsigned span = (unsigned)(slots / nx) + 2; // m-tiles of one round (+ slack): a longer tail is a prefill problem of its own, not a trim
+    for (unsigned cut = 1; cut < ny && cut <= span; ++cut) {
+        const unsigned ny1 = ny - cut, m1 = ny1 * bm, m2 = m - m1;
+        const double tail = 8.0 + std::max(w_us, 2.0 * m2 * (double)n * k / 0.8e9);
+        const double cost = rounds((double)nx * ny1 / slots) * t_round + tail;
+        if (cost < best)
+            best = cost, best_rows = m1;
+    }
+    return best < 0.95 * whole ? best_rows : 0;
+}
+
 // A process-wide opt-in for call sites that cannot name a sentinel (an unchanged SGLang / vLLM layer calls mul_mxfp4_a16(..., -1)):
 // $PETIT_AMD_MXFP4_ACTIVATIONS = mxfp8 | mxfp6 | mxfp4, or petit_set_mxfp4_default_class(), makes PETIT_SOLUTION_AUTO on MXFP4 weights
 // mean "the default pick of THAT native class" for m >= $PETIT_AMD_NATIVE_MIN_M (default 64: below it the exact kernels are HBM-bound and
@@ -882,6 +925,21 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         entry = ch.entry, splitk = ch.splitk;
         if (!entry)
             return kErrKernelShape;
+        static thread_local bool in_row_split = false;
+        if (klass == kClassExact && !io && !in_row_split && !autotune_enabled()) {
+            if (const unsigned m1 = plan_row_split(*entry, splitk, m, n, k, arch_info(dev).num_cus)) {
+                // bulk + tail (plan_row_split): two default-pick calls on row ranges of A and C, same stream, same scratch (the launches are ordered)
+                in_row_split = true;
+                int rc = gemm_impl(b_type, c, a, b, scales, global_scale, m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
+                if (rc == kOk) {
+                    const size_t c_row = (act ? n / 2 : n) * sizeof(uint16_t), a_row = (size_t)k * sizeof(uint16_t);
+                    rc = gemm_impl(b_type, (unsigned *)((char *)c + m1 * c_row), (const unsigned *)((const char *)a + m1 * a_row), b, scales, global_scale,
+                                   m - m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
+                }
+                in_row_split = false;
+                return rc;
+            }
+        }
     } else {
         entry = find_explicit(fam, solution_id);
         if (!entry)
@@ -1056,8 +1114,18 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
             return 0;
         if (const int dflt = auto_default_class(solution_id, hints->b_type, m)) // (the process-wide default class: size the scratch it needs)
             klass = dflt;
-        const AutoChoice ch = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, klass);
-        return ch.entry ? workspace_need(*ch.entry, ch.splitk, m, n, k) : 0;
+        const int dev = current_device();
+        const AutoChoice ch = choose_auto(fam, dev, hints->a_type, hints->b_type, act, m, n, k, klass);
+        if (!ch.entry)
+            return 0;
+        if (klass == kClassExact && !autotune_enabled()) {
+            if (const unsigned m1 = plan_row_split(*ch.entry, ch.splitk, m, n, k, arch_info(dev).num_cus)) { // bulk + tail share the scratch
+                const AutoChoice c1 = choose_auto(fam, dev, hints->a_type, hints->b_type, act, m1, n, k, klass);
+                const AutoChoice c2 = choose_auto(fam, dev, hints->a_type, hints->b_type, act, m - m1, n, k, klass);
+                return std::max(c1.entry ? workspace_need(*c1.entry, c1.splitk, m1, n, k) : 0, c2.entry ? workspace_need(*c2.entry, c2.splitk, m - m1, n, k) : 0);
+            }
+        }
+        return workspace_need(*ch.entry, ch.splitk, m, n, k);
     }
     const SolutionEntry *e = find_explicit(fam, solution_id);
     const unsigned splitk = solution_splitk(solution_id);
@@ -1244,6 +1312,21 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
 
 uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k) {
     return petit_gemm_resolve_solution(hints, m, n, k, PETIT_SOLUTION_AUTO, nullptr, UINT64_MAX);
+}
+
+unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue) {
+    Family fam;
+    bool ok;
+    const bool act = epilogue_act(epilogue, &ok);
+    if (!ok || !hints)
+        return 0;
+    const petit_solution_hints eff = effective_hints(hints);
+    if (eff.c_type != eff.a_type || !family_for(eff.a_type, eff.b_type, &fam) || !shape_ok(n, k) || m == 0 || m > kMaxM || autotune_enabled() ||
+        auto_default_class(PETIT_SOLUTION_AUTO, eff.b_type, m))
+        return 0;
+    const int dev = current_device();
+    const AutoChoice ch = choose_auto(fam, dev, eff.a_type, eff.b_type, act, m, n, k, kClassExact);
+    return ch.entry ? plan_row_split(*ch.entry, ch.splitk, m, n, k, arch_info(dev).num_cus) : 0;
 }
 
 int petit_repack_nvfp4_weights(unsigned *output, const unsigned *input, unsigned in_chan, unsigned out_chan,

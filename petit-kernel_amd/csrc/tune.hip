@@ -30,7 +30,7 @@
 namespace petit_amd {
 namespace {
 
-// |x - ref| <= tol * max(floor, |ref|) for every element, NaN / inf must agree; *bad counts violations.  floor = the rms of the reference
+// |x - ref| <= tol * max(floor, |ref|) for every element (inf saturated to the largest finite value), NaN must agree; *bad counts violations.  floor = the rms of the reference
 // output (tune_problem): two exact kernels differ by f32 summation order and one 16-bit rounding -- a fraction of the VALUE where the value
 // is large, of the output's rms where the terms cancel (with max(1, |ref|) as the floor every large-M kernel failed against the streaming
 // reference on K = 28672 with MXFP4 block scales up to 2^8: rms ~ 5e4, cancelling elements off by ~1 -- and the tuner crowned a streaming kernel
@@ -47,8 +47,14 @@ __global__ __launch_bounds__(256) void compare_outputs_kernel(const unsigned sho
             const unsigned short ha = x[i], hb = ref[i];
             a = (float)__builtin_bit_cast(_Float16, ha), b = (float)__builtin_bit_cast(_Float16, hb);
         }
-        const bool fa = __builtin_isfinite(a), fb = __builtin_isfinite(b);
-        if (fa != fb || (fa && !(fabsf(a - b) <= tol * fmaxf(floor_, fabsf(b)))))
+        // +-inf saturates to the type's largest finite value before the comparison: an fp16 output near 65504 rounds to inf under one summation order
+        // and stays finite under another (both exact kernels), and with "inf must agree" every large-M kernel lost to the streaming reference on
+        // fp16 x MXFP4 problems with K >= 12800, whose synthetic outputs reach that range -- 33 prefill rows of the table named a kernel ten times
+        // slower than the tiled ones (round 5, found when the rows were re-measured).  NaN must still agree.
+        const float top = is_bf16 ? 3.3895314e38f : 65504.0f;
+        const bool na = a != a, nb = b != b;
+        a = fminf(fmaxf(a, -top), top), b = fminf(fmaxf(b, -top), top);
+        if (na != nb || (!na && !(fabsf(a - b) <= tol * fmaxf(floor_, fabsf(b)))))
             ++local;
     }
     if (local)

@@ -1409,6 +1409,50 @@ def test_bench_cells_parity(pk):
     assert ran == len(plan)
 
 
+def test_auto_row_split_matches_oracle(pk):
+    """A default-pick call at a ragged prefill M runs as bulk + tail (csrc/api.hip plan_row_split, petit_gemm_auto_row_split): both launches write their
+    row ranges of C, the scratch the library asks for covers both, and every row -- the boundary rows of the split, the tail, sampled bulk rows -- matches
+    the oracle; with bias and with the SiLU-mul epilogue (C has n / 2 columns: the tail's row offset follows).  An explicit id never splits."""
+    cases = [("nv", 8192, 8192, 1100, True), ("nv", 8192, 8192, 2084, True), ("mx", 8192, 28672, 2084, True), ("nv", 8192, 8192, 600, False),
+             ("nv", 8192, 28672, 2200, True)]
+    ran = 0
+    for kind, n, k, m, is_bf16 in cases:
+        P = FullSizeProblem(pk, kind, n, k, 31 * n + k + m)
+        h = P.hints(is_bf16)
+        m1 = pk.ops.auto_row_split(h, m, n, k)
+        if not m1:
+            continue   # (the arch table changed under this case: the others still cover the path)
+        assert 0 < m1 < m and pk.ops.auto_row_split(h, m1, n, k) == 0, (kind, n, k, m, m1)
+        need = pk.ops.workspace_bytes(h, m, n, k, -1)
+        assert need >= max(pk.ops.workspace_bytes(h, m1, n, k, -1), 0) and need <= 4 * m * n * 4
+        a = P.activations(m, is_bf16, 77 + m)
+        rows = np.unique(np.concatenate([np.arange(m1 - 40, min(m, m1 + 140)), np.arange(m - 32, m), np.arange(32), np.random.default_rng(m).integers(0, m, 64)]))
+        sel = torch.from_numpy(rows).to(DEV)
+        c = P.run(a, is_bf16)
+        P.check_sampled(c[sel], a[rows], is_bf16, f"row split {kind} {n}x{k} M={m} -> {m1} + {m - m1}")
+        # the same through the explicit id of the whole problem's pick (one launch): same numbers up to the kernels' summation order
+        sid = pk.ops.resolve_solution(h, m, n, k, -1)
+        c1 = P.run(a, is_bf16, sid)
+        assert torch.allclose(c[sel].float(), c1[sel].float(), rtol=2e-2, atol=2e-2 * float(c1.float().abs().mean()))
+        del c1
+        # bias + SiLU-mul
+        dtype = torch.bfloat16 if is_bf16 else torch.float16
+        x = from_bits(a, dtype).to(DEV)
+        bias = torch.randn(n, dtype=dtype, device=DEV)
+        cb = P.mul(x, P.b, P.sp, P.gsd, m, n, k, -1, bias=bias)
+        assert torch.allclose(cb[sel].float(), (c[sel].float() + bias.float()), rtol=2e-2, atol=2e-2 * float(c.float().abs().mean()) + 0.05)
+        if pk.ops.auto_row_split(h, m, n, k, activation="silu_mul"):
+            hs = P.mul(x, P.b, P.sp, P.gsd, m, n, k, -1, activation="silu_mul")
+            assert hs.shape == (m, n // 2)
+            g, u = c[sel, : n // 2].float(), c[sel, n // 2:].float()
+            want = g * torch.sigmoid(g) * u
+            assert torch.allclose(hs[sel].float(), want, rtol=3e-2, atol=3e-2 * float(want.abs().mean()) + 1e-3), f"silu_mul {kind} {n}x{k} M={m}"
+        ran += 1
+        del P, c, cb, x
+        torch.cuda.empty_cache()
+    assert ran >= 2
+
+
 def test_bench_mlp_block_cells(pk):
     """The gated-MLP cells of bench.py (tools/benchlib.py MlpBlock: Llama-3-70B gate_up -> SiLU-mul -> down at M = 512, MXFP4
     weights) at full size, through the same calls: the exact path against the oracle (sampled columns of h, then `down` on the

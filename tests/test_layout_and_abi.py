@@ -811,6 +811,33 @@ print(hex(L.petit_gemm_default_solution(C.byref(h), 300, 4352, 8192)), hex(L.pet
     assert small == row and large == (row & ~(0xF << 60)) | (1 << 60)
 
 
+def test_ragged_prefill_m_is_planned_as_bulk_plus_tail():
+    """petit_gemm_auto_row_split (csrc/api.hip plan_row_split): a default-pick call whose tile grid ends a little past a whole number of rounds runs as two
+    launches.  The plan is host arithmetic: never at M <= 512, the bulk is a whole number of 16-row tiles and shorter than M, the bulk itself is not split
+    again, the scratch the library asks for covers both parts, and the Llama-70B `down` shape at the reference's ragged M = 2084
+    (tools/benchmarks/matmul.py) is one of the cases it fires on (17 m-tiles of 128 rows x 32 n-tiles = 2.1 rounds of 256 CUs)."""
+    from petit_kernel import _lib
+    fired = 0
+    for at in (_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP16):
+        for bt in (_lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_MXFP4_E2M1):
+            h = _lib.SolutionHints(at, bt, at, 0)
+            for n, k in ((8192, 8192), (8192, 28672), (10240, 8192), (57344, 8192), (4096, 4096), (3072, 8192)):
+                for m in (1, 16, 300, 512, 520, 600, 777, 1024, 1100, 1500, 2048, 2084, 2200, 3000, 4314, 8192, 16375):
+                    m1 = _lib.lib.petit_gemm_auto_row_split(C.byref(h), m, n, k, None)
+                    if m <= 512:
+                        assert m1 == 0
+                    if not m1:
+                        continue
+                    fired += 1
+                    assert 0 < m1 < m and m1 % 16 == 0 and m - m1 <= 1024, (at, bt, n, k, m, m1)
+                    assert _lib.lib.petit_gemm_auto_row_split(C.byref(h), m1, n, k, None) == 0
+                    ws = lambda mm: int(_lib.lib.petit_gemm_workspace_bytes(C.byref(h), mm, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO)))
+                    assert ws(m) == max(ws(m1), ws(m - m1))
+    h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    assert _lib.lib.petit_gemm_auto_row_split(C.byref(h), 2084, 8192, 28672, None) == 2048
+    assert fired >= 8
+
+
 def test_problem_ranges_are_refused_not_wrapped():
     """M beyond the tables' last bucket, and a native-class problem whose quantised activations outgrow one 32-bit buffer descriptor, return
     PETIT_ERROR_PROBLEM_SHAPE before anything is launched (no GPU here: a launch would fail differently)."""

@@ -24,7 +24,7 @@ ap.add_argument("--native", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(dev)
-band = os.environ.get("PETIT_AMD_RASTER_BAND", "default")
+band = os.environ.get("PETIT_AB_TAG") or os.environ.get("PETIT_AMD_RASTER_BAND", "default")   # (any A/B the environment selects: $PETIT_AB_TAG names it)
 for fmt in a.fmts.split(","):
     for shape in a.shapes.split(","):
         n, k = SHAPES[shape]
