@@ -1409,6 +1409,58 @@ def test_bench_cells_parity(pk):
     assert ran == len(plan)
 
 
+def test_raster_band_changes_the_order_not_the_result(pk):
+    """csrc/device_common.hpp tile_of_block: the large-M kernels map blockIdx to C tiles XCD by XCD in bands of `ph` m-tiles ($PETIT_AMD_RASTER_BAND
+    overrides the per-kernel choice; read once per process, hence child processes).  Any band -- whole columns (0), one that does not divide the
+    m-tile count (3 of 9), one taller than the grid (64) -- and the default must give bit-identical outputs for the same kernel: every tile is
+    computed exactly once by exactly the same code; and the default's output matches the oracle in the parent process's tests (bench cells at
+    M = 2084 / 4314 / 16375: ragged last bands)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, hashlib
+sys.path.insert(0, r'%s'); sys.path.insert(0, r'%s')
+import torch
+import petit_kernel as pk
+m, n, k = 1100, 3584, 2048          # 9 m-tiles of 128 rows (a ragged last tile), 14 n-tiles of 256 columns
+g = torch.Generator().manual_seed(11)
+a = torch.randn((m, k), generator=g).bfloat16().cuda()
+q = torch.randint(0, 256, (n, k // 2), generator=g, dtype=torch.uint8).cuda()
+gs = torch.tensor([0.5], device='cuda')
+out = []
+for kind in ('nv', 'mx'):
+    if kind == 'nv':
+        s = (torch.rand((n, k // 16), generator=g) * 3.5 + 0.25).to(torch.float8_e4m3fn).cuda()
+        b, sp, mul = pk.repack_nvfp4(q.view(torch.int32), n, k), pk.process_nvfp4_scales(s, n, k), pk.mul_nvfp4_a16
+        fmt = pk.DataType.float4_e2m1
+    else:
+        s = torch.randint(119, 136, (n, k // 32), generator=g, dtype=torch.uint8).cuda()
+        b, sp, mul = pk.repack_mxfp4(q.view(torch.int32), n, k), pk.process_mxfp4_scales(s, n, k), pk.mul_mxfp4_a16
+        fmt = pk.DataType.mxfloat4_e2m1
+    h = pk.PetitSolutionHints(); h.a_type = h.c_type = torch.bfloat16; h.b_type = fmt
+    ids = [sid for sid in pk.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF in (8, 12) and (sid >> 60) == 1]   # tiled / wide32 / shared-unpack, unsplit
+    assert len(ids) >= 10
+    for sid in ids:
+        c = mul(a, b, sp, gs, m, n, k, sid)
+        out.append('%%s %%x %%s' %% (kind, sid, hashlib.sha256(c.view(torch.int16).cpu().numpy().tobytes()).hexdigest()))
+    if kind == 'mx':
+        c = pk.mul_mxfp4_native(a, b, sp, gs, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP8)
+        out.append('native8 %%s' %% hashlib.sha256(c.view(torch.int16).cpu().numpy().tobytes()).hexdigest())
+print('\n'.join(out))
+""" % (ROOT / "petit-kernel_amd", ROOT)
+    results = {}
+    for band in ("default", "0", "3", "64"):
+        env = {k_: v for k_, v in os.environ.items() if k_ != "PETIT_AMD_RASTER_BAND"}
+        if band != "default":
+            env["PETIT_AMD_RASTER_BAND"] = band
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        results[band] = [ln for ln in out.stdout.strip().splitlines() if ln.startswith(("nv ", "mx ", "native8 "))]
+        assert len(results[band]) >= 21
+    assert results["0"] == results["default"] and results["3"] == results["default"] and results["64"] == results["default"]
+
+
 def test_auto_row_split_matches_oracle(pk):
     """A default-pick call at a ragged prefill M runs as bulk + tail (csrc/api.hip plan_row_split, petit_gemm_auto_row_split): both launches write their
     row ranges of C, the scratch the library asks for covers both, and every row -- the boundary rows of the split, the tail, sampled bulk rows -- matches

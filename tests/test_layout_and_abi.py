@@ -811,6 +811,20 @@ print(hex(L.petit_gemm_default_solution(C.byref(h), 300, 4352, 8192)), hex(L.pet
     assert small == row and large == (row & ~(0xF << 60)) | (1 << 60)
 
 
+def test_no_prefill_row_names_a_weight_streaming_kernel():
+    """Round 5 found 33 fp16 x MXFP4 rows of the prefill buckets naming the streaming REFERENCE kernel (ten times slower than the tiled ones at M = 8192): the
+    tuner's output check demanded that inf agree, and fp16 outputs of its synthetic long-K problems sit near 65504, so every kernel with another summation order
+    than the reference was rejected (csrc/tune.hip compare_outputs_kernel now saturates).  The table's invariant since: above M = 256 every row is a kernel
+    with a tile grid -- tiled / wide32 / shared-unpack (codes 8, 12) or the batched-decode kernel (code 0, warp_partition_m 2)."""
+    text = (ROOT / "petit-kernel_amd" / "csrc" / "tuned_gfx950.inc").read_text()
+    rows = re.findall(r"^\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\},$", text, re.M)
+    big = [(int(lo), int(sid, 16)) for _, _, _, _, lo, _, sid in rows if int(lo) >= 257]
+    assert len(big) >= 4 * 92 * 4
+    for lo, sid in big:
+        code, wm = (sid >> 48) & 0xF, (sid >> 36) & 0xF
+        assert code in (8, 12) or (code == 0 and wm == 2), (lo, hex(sid))
+
+
 def test_ragged_prefill_m_is_planned_as_bulk_plus_tail():
     """petit_gemm_auto_row_split (csrc/api.hip plan_row_split): a default-pick call whose tile grid ends a little past a whole number of rounds runs as two
     launches.  The plan is host arithmetic: never at M <= 512, the bulk is a whole number of 16-row tiles and shorter than M, the bulk itself is not split
