@@ -18,7 +18,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
     n = int(rng.choice(Ns)); 
     if kind == "mx" and n % 32: n += 16
     k = int(rng.choice([256, 512, 768, 1024, 1280, 1536, 2048, 3072, 4096, 5120, 7168, 8192]))
-    m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 44, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 700, 1024, 2084]))
+    m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 44, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 600, 700, 1024, 1100, 1500, 2084, 2200]))   # (the last five: ragged prefill M, bulk + tail launches)
     if m * n * k > 4e9: continue
     a, q, s, gs = T.random_problem(kind, m, n, k, int(rng.integers(1 << 30)), is_bf16)
     mode = rng.choice(["auto", "explicit", "explicit", "bias", "silu", "fp6", "fp8", "fp4"]) if kind == "mx" else rng.choice(["auto", "explicit", "explicit", "bias", "silu"])
