@@ -1439,7 +1439,7 @@ for kind in ('nv', 'mx'):
         b, sp, mul = pk.repack_mxfp4(q.view(torch.int32), n, k), pk.process_mxfp4_scales(s, n, k), pk.mul_mxfp4_a16
         fmt = pk.DataType.mxfloat4_e2m1
     h = pk.PetitSolutionHints(); h.a_type = h.c_type = torch.bfloat16; h.b_type = fmt
-    ids = [sid for sid in pk.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF in (8, 12) and (sid >> 60) == 1]   # tiled / wide32 / shared-unpack, unsplit
+    ids = [int(sid) for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF in (8, 12) and (sid >> 60) == 1]   # tiled / wide32 / shared-unpack, unsplit
     assert len(ids) >= 10
     for sid in ids:
         c = mul(a, b, sp, gs, m, n, k, sid)

@@ -27,10 +27,10 @@ from build_table import HELDOUT  # noqa: E402
 from table_from_candidates import read  # noqa: E402
 
 # --data FILE [--data FILE ...]: tuner logs, oldest first; a problem (dtypes, M, N, K) timed in a later log is taken from THAT log alone (a newer
-# library has kernels the older log never timed).  Default: the round-4 full log, then round 5's held-out log (every M bucket incl. prefill, the
-# batched-decode kernels in).
+# library has kernels the older log never timed).  Default: the round-4 full log, then round 5's LAST held-out log (every M bucket incl. prefill, the
+# batched-decode kernels, the band raster and the saturating output check in: session 20).
 datas = [Path(sys.argv[i + 1]) for i, a in enumerate(sys.argv) if a == "--data"] or \
-        [p for p in (ROOT / "profiles" / "r04_table_candidates.csv.gz", ROOT / "profiles" / "r05_heldout_candidates.csv.gz") if p.exists()]
+        [p for p in (ROOT / "profiles" / "r04_table_candidates.csv.gz", ROOT / "profiles" / "r05_heldout_final_candidates.csv.gz") if p.exists()]
 best, cands = {}, {}
 for data in datas:
     b, c = read(data)
