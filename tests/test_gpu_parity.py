@@ -1409,6 +1409,32 @@ def test_bench_cells_parity(pk):
     assert ran == len(plan)
 
 
+def test_prefill_default_picks_run_at_compute_speed(pk):
+    """A perf regression guard, not a benchmark: round 5 found 33 prefill rows of the fp16 x MXFP4 family naming the streaming reference kernel (10 ms where the
+    tiled kernels take 1.0: the tuner's output check had rejected everything else), in a family x regime no bench cell and no test timed.  Every family's default
+    pick at M = 4096 on a long-K and a wide shape must reach 500 TFLOP/s (they measure 900-1400; the bug read ~100)."""
+    m = 4096
+    for kind in ("nv", "mx"):
+        for n, k in ((8192, 28672), (10240, 8192)):
+            P = FullSizeProblem(pk, kind, n, k, 5 * n + k)
+            for is_bf16 in (True, False):
+                dtype = torch.bfloat16 if is_bf16 else torch.float16
+                x = (torch.randn((m, k), device=DEV) * 0.05).to(dtype)
+                for _ in range(2):
+                    P.mul(x, P.b, P.sp, P.gsd, m, n, k, -1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    P.mul(x, P.b, P.sp, P.gsd, m, n, k, -1)
+                e1.record()
+                torch.cuda.synchronize()
+                tflops = 3 * 2.0 * m * n * k / (e0.elapsed_time(e1) * 1e-3) / 1e12
+                picked = pk.ops.resolve_solution(P.hints(is_bf16), m, n, k, -1)
+                assert tflops >= 500.0, f"{'bf16' if is_bf16 else 'fp16'} x {kind} {n}x{k} M={m}: {tflops:.0f} TFLOP/s with {picked:#x}"
+            del P
+            torch.cuda.empty_cache()
+
+
 def test_raster_band_changes_the_order_not_the_result(pk):
     """csrc/device_common.hpp tile_of_block: the large-M kernels map blockIdx to C tiles XCD by XCD in bands of `ph` m-tiles ($PETIT_AMD_RASTER_BAND
     overrides the per-kernel choice; read once per process, hence child processes).  Any band -- whole columns (0), one that does not divide the
