@@ -73,6 +73,8 @@ def bench_cell_plan() -> list:
                      dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp6"),
                      dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp4"),
                      dict(shape=shape, M=m, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=m, a="fp8", w="dense", mode="hipblaslt_fp8")]
+        # (fp16 x MXFP4 at the largest chunk: the family x regime whose table rows named a 10 x slower kernel until round 5 re-measured them -- no cell had timed it)
+        plan += [dict(shape=shape, M=PREFILL_MS[-1], a="fp16", w="mx", mode="auto")]
     # launch-gap-bound shapes: the q / k / v shards of a TP-8 deployment (1280 x 8192 each) as three launches and as one grouped launch
     plan += [dict(shape="tp8_qkv_3x1280", M=m, a="bf16", w="nv", mode=mode) for m in (1, 16) for mode in ("separate", "grouped")]
     # the gated-MLP block (gate_up -> SiLU-mul -> down) as a unit: what the quantising epilogue buys the native class
