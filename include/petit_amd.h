@@ -177,6 +177,11 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
  * the problem as a whole; resolve them at (rows) and (m - rows) for the two launches.  No reference counterpart: the reference's
  * 234-kernel chooser (fp4/algo_chooser.cc:64-132) takes the grid as it comes. */
 unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue);
+/* A test aid: the C tile (n-tile column *bn, m-tile row *bm) that workgroup `block` (= blockIdx.y * gridDim.x + blockIdx.x) of an nx x ny grid of the
+ * large-M kernels computes under the XCD-aware raster with bands of `band` m-tiles (0 = whole columns) -- the very function the kernels call
+ * (csrc/device_common.hpp tile_of_linear), so that its bijection is checked without a GPU.  No reference counterpart (the reference's grid is
+ * blockIdx as is, gemm_fp4_fp16_grid.cuh:554-555). */
+void petit_raster_tile(unsigned nx, unsigned ny, unsigned band, unsigned block, unsigned *bn, unsigned *bm);
 
 /*
  * Offline repack of checkpoint tensors into the packed layout the GEMM reads

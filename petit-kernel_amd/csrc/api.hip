@@ -1314,6 +1314,16 @@ uint64_t petit_gemm_default_solution(const petit_solution_hints *hints, unsigned
     return petit_gemm_resolve_solution(hints, m, n, k, PETIT_SOLUTION_AUTO, nullptr, UINT64_MAX);
 }
 
+void petit_raster_tile(unsigned nx, unsigned ny, unsigned band, unsigned block, unsigned *bn, unsigned *bm) {
+    unsigned n_ = 0, m_ = 0;
+    if (nx && ny && block < nx * ny)
+        tile_of_linear(block, nx, ny, kFlagXcdRaster | ((band & 0xffu) << kFlagBandShift), n_, m_);
+    if (bn)
+        *bn = n_;
+    if (bm)
+        *bm = m_;
+}
+
 unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue) {
     Family fam;
     bool ok;

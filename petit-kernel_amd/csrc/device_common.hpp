@@ -320,13 +320,14 @@ __device__ __forceinline__ unsigned physical_tile(unsigned l, unsigned ntiles, u
 // XCD-aware raster gives each XCD a contiguous chunk of the tile list, m-blocks fastest: the tiles an XCD runs at the
 // same time are a few weight panels x ALL their m-blocks, so a panel leaves HBM once per XCD-chunk instead of once per
 // m-block (M = 512, gate_up: 1.06 GB -> ~0.3 GB per launch).  A pure speed choice: any placement computes the same.
-__device__ __forceinline__ void tile_of_block(unsigned flags, unsigned &bn, unsigned &bm) {
-    const unsigned nx = gridDim.x, ny = gridDim.y;
+// Where the large-M kernels put the workgroup with linear id b = blockIdx.y * gridDim.x + blockIdx.x of an nx x ny grid: pure arithmetic, host + device, so the
+// bijection is tested on the CPU through petit_raster_tile (tests/test_layout_and_abi.py) and the kernels and the test run the SAME lines.
+__host__ __device__ inline void tile_of_linear(unsigned b, unsigned nx, unsigned ny, unsigned flags, unsigned &bn, unsigned &bm) {
     if (!(flags & kFlagXcdRaster)) {
-        bn = blockIdx.x, bm = blockIdx.y;
+        bm = b / nx, bn = b - bm * nx;
         return;
     }
-    const unsigned b = blockIdx.y * nx + blockIdx.x, nwg = nx * ny;
+    const unsigned nwg = nx * ny;
     const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, idx = b >> 3;
     const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx; // bijective for any nwg
     // An XCD's tiles are consecutive in t and its 32 CUs run 32 consecutive ones at a time.  Column-major t (m fastest)
@@ -339,8 +340,11 @@ __device__ __forceinline__ void tile_of_block(unsigned flags, unsigned &bn, unsi
         return;
     }
     const unsigned band = t / (ph * nx), tl = t - band * ph * nx;
-    const unsigned rows = min(ph, ny - band * ph);
+    const unsigned left = ny - band * ph, rows = ph < left ? ph : left;
     bn = tl / rows, bm = band * ph + (tl - bn * rows);
+}
+__device__ __forceinline__ void tile_of_block(unsigned flags, unsigned &bn, unsigned &bm) {
+    tile_of_linear(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, flags, bn, bm);
 }
 
 // Two waves share a SIMD in the 2-workgroups-per-CU kernels, run the same phases (unpack burst, MFMA burst, barrier) and,

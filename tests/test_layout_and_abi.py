@@ -811,6 +811,32 @@ print(hex(L.petit_gemm_default_solution(C.byref(h), 300, 4352, 8192)), hex(L.pet
     assert small == row and large == (row & ~(0xF << 60)) | (1 << 60)
 
 
+def test_raster_maps_every_workgroup_to_its_own_tile():
+    """petit_raster_tile = csrc/device_common.hpp tile_of_linear, the function the large-M kernels call with their blockIdx: for any grid and any band height
+    (0 = whole columns, bands that do not divide the m-tile count, bands taller than the grid) the map workgroup -> C tile is a bijection onto the grid; and
+    with a band of 4 the 32 workgroups an XCD runs at a time (linear ids b, b + 8, ...: one XCD) cover at most 4 m-tiles x 9 n-tiles -- the point of the band."""
+    from petit_kernel import _lib
+    bn, bm = C.c_uint(0), C.c_uint(0)
+
+    def tile(nx, ny, band, b):
+        _lib.lib.petit_raster_tile(nx, ny, band, b, C.byref(bn), C.byref(bm))
+        return bn.value, bm.value
+    for nx in (1, 3, 7, 32, 40, 224):
+        for ny in (1, 2, 5, 9, 17, 34, 128):
+            for band in (0, 1, 2, 3, 4, 8, 32, 200):
+                seen = {tile(nx, ny, band, b) for b in range(nx * ny)}
+                assert len(seen) == nx * ny and all(x < nx and y < ny for x, y in seen), (nx, ny, band)
+    for nx, ny in ((224, 128), (32, 128), (40, 17)):
+        for start in (0, 8 * 32 * 5, 8 * 32 * 11):
+            if start + 8 * 32 > nx * ny:
+                continue
+            for xcd in range(8):
+                tiles = [tile(nx, ny, 4, start + xcd + 8 * i) for i in range(32)]
+                assert len({y for _, y in tiles}) <= 4 and len({x for x, _ in tiles}) <= 9, (nx, ny, start, xcd)
+                whole = [tile(nx, ny, 0, start + xcd + 8 * i) for i in range(32)]
+                assert ny < 32 or len({x for x, _ in whole}) <= 2    # whole columns: one W panel, 32 A panels -- what rounds 2-4 did
+
+
 def test_no_prefill_row_names_a_weight_streaming_kernel():
     """Round 5 found 33 fp16 x MXFP4 rows of the prefill buckets naming the streaming REFERENCE kernel (ten times slower than the tiled ones at M = 8192): the
     tuner's output check demanded that inf agree, and fp16 outputs of its synthetic long-K problems sit near 65504, so every kernel with another summation order
