@@ -449,7 +449,7 @@ def test_unseen_shapes_stay_close_to_the_measured_best():
     ten shapes that tools/build_table.py kept out of the table against every candidate the in-library tuner timed on them on MI355X in a LATER session than the
     ones the table was built in (profiles/r05_heldout_final_candidates.csv.gz, all 13 M buckets incl. prefill; round 4 replayed the table-building session itself,
     which flatters the picks): within 6 % of the best kernel in the median of every M bucket, 12 % at the 90th percentile overall, 25 % at the 90th percentile of
-    every bucket, never worse than 1.6 x -- one single-sample glitch included -- (the neighbours are ranked by how their kernels' grids fit THIS problem: api.hip grid_overhead); (2) the formula heuristic behind
+    every bucket, never worse than 1.4 x (the neighbours are ranked by how their kernels' grids fit THIS problem: api.hip grid_overhead); (2) the formula heuristic behind
     it (table disabled), on the round-4 log of all 3680 tabulated problems: median within 4 %, 90 % within 25 %."""
     import subprocess
     import sys
@@ -461,7 +461,7 @@ def test_unseen_shapes_stay_close_to_the_measured_best():
         buckets = [tuple(float(x) for x in b) for b in re.findall(r"^\| \d+-\d* \| \d+ \| ([0-9.]+) \| ([0-9.]+) \| ([0-9.]+) \|$", out, re.M)]
         return tuple(float(x) for x in m.groups()), buckets, out
     (median, p90, worst), buckets, out = run("--heldout", "--by-m", "--mode", "nearest")
-    assert len(buckets) == 13 and median <= 1.02 and p90 <= 1.12 and worst <= 1.60 and all(b[0] <= 1.06 for b in buckets), out
+    assert len(buckets) == 13 and median <= 1.02 and p90 <= 1.12 and worst <= 1.40 and all(b[0] <= 1.06 for b in buckets), out
     assert all(b[1] <= 1.25 for b in buckets), out                     # the tail: p90 of every bucket (measured 1.06-1.25; 1.05-1.35 with the nearest row taken blindly)
     (median, p90, _), buckets, out = run("--by-m", "--data", str(ROOT / "profiles" / "r04_table_candidates.csv.gz"))
     assert len(buckets) == 10 and median <= 1.04 and p90 <= 1.25 and all(b[0] <= 1.06 for b in buckets), out
