@@ -597,10 +597,10 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
             const double rounds = r <= 1.0 ? 1.0 : 0.5 * (r + (double)(unsigned long)(r + 0.999999));
             return rounds * slots * bm * bn / ((double)mm * n); // (work paid for / work asked for: ragged edges count too)
         };
-        unsigned lo = 0, hi = 0;
+        unsigned hi = 0;
         for (int i = 0; i < n_alt; ++i)
             if (alt[i].solution == tuned && m >= alt[i].m_lo && m <= alt[i].m_hi)
-                lo = alt[i].m_lo, hi = alt[i].m_hi;
+                hi = alt[i].m_hi;
         const unsigned rep = hi == 0 ? m : hi > 4096 ? 8192u : hi == 4096 ? 2048u : hi; // the M the row was measured at (tools/make_tuned_inc.py BUCKET)
         const double own = waste(*c.entry, m);
         if (own > 1.08 * waste(*c.entry, rep)) {
