@@ -74,6 +74,11 @@ if pre:
 if any(k[1] == 256 for k in cells):
     print("\nfp16 x NVFP4 at M = 256 (the reference benchmark's middle column): " +
           ", ".join(f"{s} {cells[(s, 256, 'fp16xnv')]['us']:.1f} us = {cells[(s, 256, 'fp16xnv')]['TF']:.0f} TFLOP/s" for s in shapes if (s, 256, "fp16xnv") in cells) + ".")
+big = [k for k in cells if k[2] == "fp16xmx" and k[1] > 512]
+if big:
+    m_big = max(k[1] for k in big)
+    print(f"\nfp16 x MXFP4 at M = {m_big} (the family x regime of round 5's tuner-check bug): " +
+          ", ".join(f"{s} {cells[(s, m_big, 'fp16xmx')]['us']:.0f} us = {cells[(s, m_big, 'fp16xmx')]['TF']:.0f} TFLOP/s" for s in shapes if (s, m_big, "fp16xmx") in cells) + ".")
 print("\nLaunch-gap-bound shapes and the MLP block:\n\n| cell | us | rate |\n|---|---|---|")
 for (s, m, dt), c in cells.items():
     if s.startswith("tp8"):
