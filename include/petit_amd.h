@@ -76,7 +76,8 @@ typedef struct petit_solution_hints {
 /* "Let the library choose": the reference's (unsigned long)-1 sentinel,
  * fp4/gemm_fp4_fp16_grid.cc:46-48. */
 #define PETIT_SOLUTION_AUTO UINT64_MAX
-/* "Let the library choose INSIDE the native-FP4 class" (MXFP4 entry points only; see "Native-FP4 kernels" below): the caller
+/* "Let the library choose INSIDE the native-FP4 class" (MXFP4 entry points; NVFP4 entry points once the weights have an MFMA-native image attached --
+ * "NVFP4 weights on the native class" below; see "Native-FP4 kernels"): the caller
  * opts into quantised activations by naming the sentinel -- MXFP8 activations (FP4 x FP8 block-scaled MFMA), MXFP6 (e2m3
  * elements: the three mantissa bits of e4m3 at the instruction's FP4 rate) or MXFP4 activations (FP4 x FP4).  Needs per-call scratch (petit_gemm_workspace_bytes with the same sentinel); without it the call
  * returns PETIT_ERROR_KERNEL_SHAPE rather than silently running another accuracy class.  The Python layers spell them
@@ -363,6 +364,51 @@ uint64_t petit_gemm_native_workspace_bytes(const petit_solution_hints *hints, un
  * both pointers 16-byte aligned. */
 uint64_t petit_quantized_activation_bytes(unsigned m, unsigned k, int format);
 int petit_quantize_activations(void *qa, const void *a, unsigned m, unsigned k, int a_type, int format, void *stream);
+
+/*
+ * NVFP4 weights on the native class (no counterpart in the reference; BASELINE north_star: "a native fp4/fp8 MFMA variant").
+ *
+ * NVFP4's e4m3 group-16 scales do not fit the block-scaled MFMA (one E8M0 scale per 32 k), and multiplying the e4m3 mantissa into the elements
+ * inside the GEMM costs what the exact kernels' unpack costs (petit-kernel_amd/csrc/nvnative.hip has the arithmetic).  So the weights are
+ * re-encoded ONCE, at load time, into an MFMA-native image ("petit-cdna4-nv6/1", csrc/layout.h): per 32-k block of a weight row one E8M0 scale
+ * 2^E, E = floor(log2(max |fp4 x e4m3|)) - 2, and FP6 e2m3 elements RNE(fp4 x e4m3 / 2^E) -- 6.25 bits per weight next to the 4.5 of the packed
+ * tensors, which the exact kernels (every decode call) keep reading.  The instruction then runs at the rate of the ACTIVATION format: MXFP6 / MXFP4
+ * activations at the FP4 rate, MXFP8 at the FP8 rate; global_scale stays in the epilogue.
+ *
+ * Accuracy class: the native class's (quantised activations, see above) PLUS the re-rounding of the weights: fp4 x e4m3 has up to 6 significant
+ * bits, e2m3 keeps 4, and the group with the smaller scale of a block loses one more bit per binade of distance.  Per element
+ *     |w_image - w_nvfp4| <= 2^-4 |w_nvfp4|  (elements >= 2^E, i.e. within 3 binades of the block maximum),   <= 2^(E-4)  below,
+ * hence per output |c_image - c_nvfp4| <= gs * sum_k |a_k| * max(2^-4 |w_k|, 2^(E_k - 4)).  On weights quantised by the checkpoint recipe
+ * (tools/quantize_weights.py) 22-38 % of the elements move, by 2.3 % rms of the weight: the weight's total quantisation error goes from 9.51 % to
+ * 9.79 % of its rms (profiles/r06_nv6_reencode.md; MLP / stacked budgets: profiles/r06_*accuracy_budget*.json).  Given the image and the
+ * quantised activations the kernels are exact in the sense of "Exactness of the class" above (same instruction, same bound).
+ *
+ *   petit_nvfp4_native_image_bytes(in_chan = K, out_chan = N)    bytes of the image (0 for a shape the class does not take: N % 16, K % 256)
+ *   petit_nvfp4_native_image(image, b, scales, K, N, stream)     device: from the PACKED tensors of petit_repack_nvfp4_weights / _scales;
+ *                                                                image 256-byte aligned; N * K * 3 / 4 < 2^32
+ *   petit_nvfp4_native_image_host                                host twin, bit-identical (offline conversion; packed host tensors from
+ *                                                                petit_repack_nvfp4_*_host)
+ *   petit_nvfp4_native_image_dequant_host(out, image, K, N)      test / debug aid: out[n][k] f32 = element x 2^(scale - 127), no global scale
+ *
+ * Running it -- two ways, same kernels:
+ *   petit_gemm_nvfp4_native(c, a, image, ...)   names the image per call; solution_id = PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP6 / _MXFP4 (the
+ *       activation format) or an explicit native id of the NVFP4 family; native / workspace exactly as petit_gemm_mxfp4_native (pre-quantised
+ *       activations, the quantising SiLU-mul epilogue, petit_gemm_native_workspace_bytes with hints->b_type = PETIT_DTYPE_FP4_E2M1).
+ *   petit_nvfp4_native_attach(b, image)         for call sites that keep calling the reference's entry point: afterwards
+ *       petit_gemm_fp4_fp16_grid_ws(c, a, b, scales, ..., PETIT_SOLUTION_AUTO_NATIVE_*, ...) -- mul_nvfp4_a16(..., solution_id = -2 / -3 / -4) --
+ *       runs on the image attached to `b`.  The image stays the caller's memory and must outlive the attachment; image = NULL detaches.  A
+ *       sentinel (or explicit native id) on weights without an image returns PETIT_ERROR_KERNEL_SHAPE -- never another accuracy class.
+ * PETIT_SOLUTION_AUTO on NVFP4 weights is never affected: it stays the exact class.
+ */
+uint64_t petit_nvfp4_native_image_bytes(unsigned in_chan, unsigned out_chan);
+int petit_nvfp4_native_image(void *image, const unsigned *b, const unsigned *scales, unsigned in_chan, unsigned out_chan, void *stream);
+int petit_nvfp4_native_image_host(void *image, const unsigned *b, const unsigned *scales, unsigned in_chan, unsigned out_chan);
+int petit_nvfp4_native_image_dequant_host(float *out, const void *image, unsigned in_chan, unsigned out_chan);
+int petit_nvfp4_native_attach(const void *b, const void *image);
+const void *petit_nvfp4_native_attached(const void *b);
+int petit_gemm_nvfp4_native(void *c, const void *a, const void *image, const float *global_scale, unsigned m, unsigned n, unsigned k,
+                            const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
+                            const petit_native_args *native, void *workspace, uint64_t workspace_bytes, void *stream);
 
 /*
  * Grouped launch (no counterpart in the reference): up to PETIT_GROUP_MAX weight matrices that share the activation rows --

@@ -242,3 +242,32 @@ def petit_dequant(w_packed: np.ndarray, s_packed: np.ndarray, fmt: str, n: int, 
     if rc != 0:
         raise ValueError("bad shape for petit_dequant")
     return out
+
+
+# --- the MFMA-native image of NVFP4 weights ("petit-cdna4-nv6/1"): a statement of THIS build's load-time re-encoding (petit-kernel_amd/csrc/nvnative.hip,
+# include/petit_amd.h "NVFP4 weights on the native class"), not of anything in the reference: it is what the native-class tests run the oracle GEMM on.
+
+E2M3_GRID = np.array([i / 8.0 for i in range(8)] + [(1.0 + i / 8.0) * 2.0 ** e for e in range(3) for i in range(8)])
+
+
+def e2m3_rne(x: np.ndarray) -> np.ndarray:
+    """nearest e2m3 value (grid 0, 1/8 .. 7/8, 1 .. 1.875, 2 .. 3.75, 4 .. 7.5), ties to the even code, saturating at 7.5; sign kept."""
+    ax = np.abs(np.asarray(x, dtype=np.float64))
+    idx = np.searchsorted(E2M3_GRID, ax, side="left").clip(1, 31)
+    lo, hi = E2M3_GRID[idx - 1], E2M3_GRID[idx]
+    pick_hi = (ax - lo > hi - ax) | ((ax - lo == hi - ax) & (idx % 2 == 0))       # grid index = code: ties go to the even code
+    return np.sign(x) * np.where(ax >= 7.5, 7.5, np.where(pick_hi, hi, lo))
+
+
+def nv6_reencode(q_u8: np.ndarray, s_e4m3_bits: np.ndarray):
+    """NVFP4 (q uint8 [N, K/2], e4m3 scale bytes [N, K/16]) -> (w [N, K] f32: the image's values WITHOUT the global scale, scale bytes [N, K/32]).
+    Per 32-k block: v = fp4 x e4m3 (exact), E = floor(log2 max|v|) - 2, element = RNE_e2m3(v / 2^E), byte = E + 127 (127 for a zero block)."""
+    v = dequant_nvfp4(q_u8, s_e4m3_bits).astype(np.float64)
+    n, k = v.shape
+    blk = v.reshape(n, k // 32, 32)
+    amax = np.abs(blk).max(axis=2)
+    ebits = (amax.astype(np.float32).view(np.uint32) >> 23) & 0xFF
+    sbyte = np.where(amax == 0, 127, ebits.astype(np.int64) - 2)
+    scale = np.ldexp(1.0, sbyte - 127)[:, :, None]
+    w = e2m3_rne(blk / scale) * scale
+    return w.reshape(n, k).astype(np.float32), sbyte.astype(np.uint8)

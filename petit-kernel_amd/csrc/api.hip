@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -46,8 +48,8 @@ static const SolutionEntry *concat_parts(std::vector<SolutionEntry> &store, std:
         *count = (int)store.size();                                                                           \
         return table;                                                                                         \
     }
-PETIT_FAMILY_TABLE(nv_bf16, solutions_nv_bf16_p1, solutions_nv_bf16_p2, solutions_nv_bf16_p3, solutions_nv_bf16_p4, solutions_nv_bf16_p6)
-PETIT_FAMILY_TABLE(nv_f16, solutions_nv_f16_p1, solutions_nv_f16_p2, solutions_nv_f16_p3, solutions_nv_f16_p4, solutions_nv_f16_p6)
+PETIT_FAMILY_TABLE(nv_bf16, solutions_nv_bf16_p1, solutions_nv_bf16_p2, solutions_nv_bf16_p3, solutions_nv_bf16_p4, solutions_nv_bf16_p5, solutions_nv_bf16_p6)
+PETIT_FAMILY_TABLE(nv_f16, solutions_nv_f16_p1, solutions_nv_f16_p2, solutions_nv_f16_p3, solutions_nv_f16_p4, solutions_nv_f16_p5, solutions_nv_f16_p6)
 PETIT_FAMILY_TABLE(mx_bf16, solutions_mx_bf16_p1, solutions_mx_bf16_p2, solutions_mx_bf16_p3, solutions_mx_bf16_p4, solutions_mx_bf16_p5, solutions_mx_bf16_p6)
 PETIT_FAMILY_TABLE(mx_f16, solutions_mx_f16_p1, solutions_mx_f16_p2, solutions_mx_f16_p3, solutions_mx_f16_p4, solutions_mx_f16_p5, solutions_mx_f16_p6)
 #undef PETIT_FAMILY_TABLE
@@ -684,6 +686,24 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
     slot = Slot{key0, key1, generation, c};
     return c;
 }
+// NVFP4 weights on the native class run on their MFMA-native image (nvnative.hip, "petit-cdna4-nv6/1").  Call sites that keep calling the reference's
+// entry point with (b, scales) name the image by ATTACHING it to the packed weight pointer once at load time (petit_nvfp4_native_attach); the image
+// stays the caller's memory.  Looked up only by native-class calls on NVFP4 weights (prefill-sized problems: a mutex and a hash probe).
+struct ImageRegistry {
+    std::mutex mu;
+    std::unordered_map<const void *, const void *> map;
+};
+ImageRegistry &image_registry() {
+    static ImageRegistry r;
+    return r;
+}
+const void *attached_image(const void *b) {
+    ImageRegistry &r = image_registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    const auto it = r.map.find(b);
+    return it == r.map.end() ? nullptr : it->second;
+}
+
 int auto_class(uint64_t solution_id) {
     return solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP8   ? kClassNativeFp8
            : solution_id == PETIT_SOLUTION_AUTO_NATIVE_MXFP6 ? kClassNativeFp6
@@ -799,8 +819,8 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
                     int cap) {
     Family fam;
     b_type = canonical_b_type(b_type);
-    if (!family_for(a_type, b_type, &fam) || !shape_ok(n, k) || m == 0 || (klass != kClassExact && b_type != kDataTypeMxFp4e2m1))
-        return 0; // (the native class exists for MXFP4 weights only)
+    if (!family_for(a_type, b_type, &fam) || !shape_ok(n, k) || m == 0)
+        return 0;
     const unsigned nspans = k / (kTileK * span_tiles_for_k(k));
     const int num_cus = arch_info(current_device()).num_cus;
     int count = 0;
@@ -886,8 +906,6 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         return kErrProblemShape;
     // the native pipeline: pre-quantised activations / quantised SiLU-mul output (MXFP4 weights, 32x32x64 kernels only)
     const unsigned restrict_ = (a_format ? kNeedK32 : 0u) | (out_format ? kNeedQuantOut : 0u);
-    if (restrict_ && b_type != kDataTypeMxFp4e2m1)
-        return kErrKernelShape;
     if (out_format && !act)
         return kErrBadArgument; // (the quantised output is the SiLU-mul epilogue's)
     if (out_format && (n % 512 != 0 || ((uintptr_t)c & 15)))
@@ -908,8 +926,11 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
                 klass = dflt;
         }
     }
-    if (klass != kClassExact && b_type != kDataTypeMxFp4e2m1)
-        return kErrKernelShape; // the native class exists for MXFP4 weights only (e4m3 group scales are not E8M0 block scales)
+    // NVFP4 weights: the native class runs on the weights' MFMA-native image (e4m3 group scales are not E8M0 block scales: nvnative.hip), handed
+    // over by petit_gemm_nvfp4_native or attached to `b` beforehand; without one the call is refused, never served by another accuracy class
+    const void *nv_image = b_type != kDataTypeFp4e2m1 ? nullptr : (io && io->image) ? io->image : klass != kClassExact ? attached_image(b) : nullptr;
+    if (klass != kClassExact && b_type == kDataTypeFp4e2m1 && !nv_image)
+        return kErrKernelShape;
     // the native kernels read the quantised activations (k-tile major, up to m * k bytes) through ONE 32-bit buffer descriptor, and the
     // quantiser's grid has one row per activation row
     if ((klass != kClassExact || a_format) && ((uint64_t)m * k >= (1ull << 32) || m > 65535u))
@@ -970,9 +991,19 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
 
     if (is_native_am(entry->shape.am) && ((uint64_t)m * k >= (1ull << 32) || m > 65535u))
         return kErrProblemShape; // (an explicit native id: the same descriptor range as above)
+    if (is_native_am(entry->shape.am) && b_type == kDataTypeFp4e2m1) {
+        if (!nv_image)
+            nv_image = attached_image(b); // (an explicit native id)
+        if (!nv_image)
+            return kErrKernelShape; // an explicit native id on NVFP4 weights that have no image attached
+        if (nv6_elem_bytes(n, k) >= (1ull << 32))
+            return kErrProblemShape; // (the image's element part is read through one 32-bit buffer descriptor)
+    }
 
     GemmArgs args{};
     args.c = c, args.a = a, args.w = b, args.s = scales, args.gs = global_scale;
+    if (is_native_am(entry->shape.am) && b_type == kDataTypeFp4e2m1)
+        args.w = nv_image, args.s = (const char *)nv_image + nv6_elem_bytes(n, k);
     args.m = m, args.n = n, args.k = k;
     args.bias = epilogue ? epilogue->bias : nullptr;
     args.qa = a_format ? (const void *)a : nullptr, args.qa_format = a_format, args.out_format = out_format;
@@ -1123,8 +1154,6 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
         return 0;
     if (is_auto_id(solution_id)) {
         int klass = auto_class(solution_id);
-        if (klass != kClassExact && hints->b_type != kDataTypeMxFp4e2m1)
-            return 0;
         if (const int dflt = auto_default_class(solution_id, hints->b_type, m)) // (the process-wide default class: size the scratch it needs)
             klass = dflt;
         const int dev = current_device();
@@ -1168,7 +1197,7 @@ uint64_t petit_gemm_native_workspace_bytes(const petit_solution_hints *hints, un
     Family fam;
     bool ok;
     const bool act = epilogue_act(epilogue, &ok);
-    if (!ok || !native_args_ok(native) || !hints || hints->c_type != hints->a_type || hints->b_type != kDataTypeMxFp4e2m1 ||
+    if (!ok || !native_args_ok(native) || !hints || hints->c_type != hints->a_type || (hints->b_type != kDataTypeMxFp4e2m1 && hints->b_type != kDataTypeFp4e2m1) ||
         !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0 || solution_id == PETIT_SOLUTION_AUTO)
         return 0;
     const unsigned a_format = native ? (unsigned)native->a_format : 0u, out_format = native ? (unsigned)native->out_format : 0u;
@@ -1183,6 +1212,50 @@ uint64_t petit_gemm_native_workspace_bytes(const petit_solution_hints *hints, un
         splitk = solution_splitk(solution_id);
     }
     return e && splitk ? workspace_need(*e, splitk, m, n, k, a_format != 0) : 0;
+}
+
+uint64_t petit_nvfp4_native_image_bytes(unsigned in_chan, unsigned out_chan) {
+    return (out_chan % kTileN || in_chan % 256) ? 0 : nv6_image_bytes(out_chan, in_chan);
+}
+int petit_nvfp4_native_image(void *image, const unsigned *b, const unsigned *scales, unsigned in_chan, unsigned out_chan, void *stream) {
+    if ((!image || !b || !scales || ((uintptr_t)image & 255)) && in_chan && out_chan)
+        return kErrBadArgument;
+    return nv6_image(image, b, scales, out_chan, in_chan, (hipStream_t)stream);
+}
+int petit_nvfp4_native_image_host(void *image, const unsigned *b, const unsigned *scales, unsigned in_chan, unsigned out_chan) {
+    if ((!image || !b || !scales) && in_chan && out_chan)
+        return kErrBadArgument;
+    return nv6_image_host(image, b, scales, out_chan, in_chan);
+}
+int petit_nvfp4_native_image_dequant_host(float *out, const void *image, unsigned in_chan, unsigned out_chan) {
+    if ((!out || !image) && in_chan && out_chan)
+        return kErrBadArgument;
+    return nv6_image_dequant_host(out, image, out_chan, in_chan);
+}
+int petit_nvfp4_native_attach(const void *b, const void *image) {
+    if (!b || ((uintptr_t)image & 255))
+        return kErrBadArgument;
+    ImageRegistry &r = image_registry();
+    std::lock_guard<std::mutex> lock(r.mu);
+    if (image)
+        r.map[b] = image;
+    else
+        r.map.erase(b);
+    return kOk;
+}
+const void *petit_nvfp4_native_attached(const void *b) { return b ? attached_image(b) : nullptr; }
+
+int petit_gemm_nvfp4_native(void *c, const void *a, const void *image, const float *global_scale, unsigned m, unsigned n, unsigned k,
+                            const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue,
+                            const petit_native_args *native, void *workspace, uint64_t workspace_bytes, void *stream) {
+    if (!native_args_ok(native) || ((uintptr_t)image & 255))
+        return kErrBadArgument;
+    const NativeIo io{native ? (unsigned)native->a_format : 0u, native ? (unsigned)native->out_format : 0u, image};
+    if (solution_id == PETIT_SOLUTION_AUTO)
+        return kErrKernelShape; // this entry point is the native class's: name a sentinel or a native kernel id
+    // (b / scales: the image stands in for both -- gemm_impl reads neither once it has the image)
+    return gemm_impl(kDataTypeFp4e2m1, (unsigned *)c, (const unsigned *)a, (const unsigned *)image, (const unsigned *)image, global_scale, m, n, k, hints,
+                     solution_id, epilogue, workspace, workspace_bytes, stream, &io);
 }
 
 int petit_gemm_fp4_fp16_grouped(const petit_group_member *members, unsigned count, const unsigned *a, unsigned m, unsigned k,
@@ -1297,8 +1370,6 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
         return make_solution_id(e->shape, fam.elem_b, entry_mfma(fam, *e), sk);
     }
     int klass = auto_class(solution_id);
-    if (klass != kClassExact && hints->b_type != kDataTypeMxFp4e2m1)
-        return 0;
     if (const int dflt = auto_default_class(solution_id, hints->b_type, m)) { // the process-wide default class, when `workspace_bytes` covers its pick (gemm_impl)
         const AutoChoice chn = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, dflt);
         if (chn.entry && workspace_need(*chn.entry, chn.splitk, m, n, k) <= workspace_bytes)
@@ -1476,8 +1547,8 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
     }
     if (s.am == kNative32Am) {
         const int wm = s.wm == 2 ? 2 : 1, kgrp = s.wm == 3 ? 2 : 1, lw = s.wm == 4 ? 1 : 0;
-        snprintf(buf, len, "native32 %sxmxfp4 (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d%s d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
-                 a_type == kDataTypeBf16 ? "bf16" : "fp16", s.pa == 2 ? "mxfp4" : s.pa == 4 ? "mxfp6" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, lw ? " +loader" : "", s.d,
+        snprintf(buf, len, "native32 %sx%s (activations -> %s) ks%d mb%d np%d waves%dx%d kgroups%d%s d%d kt%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x64 scaled mfma)",
+                 a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4-image(e2m3)", s.pa == 2 ? "mxfp4" : s.pa == 4 ? "mxfp6" : "mxfp8", s.ks, s.mt / wm, s.nt / 2, wm, s.wn, kgrp, lw ? " +loader" : "", s.d,
                  s.wk / 4, s.wk % 4, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * (s.wn * wm * kgrp + lw));
         return kOk;
     }

@@ -349,9 +349,16 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
 //        only and meet the loader at the stage barrier.  Built on the hypothesis that hits queue behind misses (loads retire in issue order); worth
 //        4-13 % at M = 512, but the hypothesis itself did not survive the follow-up experiments (PETIT_N32_PW / PETIT_N32_LWPF below,
 //        profiles/r03_native_ablation.md): a CU takes in ~60-65 GB/s of this kind of stream however it is requested.
-template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1, int KG_ = 1, int LW_ = 0>
+//   WF   weight operand: 4 = MXFP4 weights RAW (the packed layout of layout.h, n-tile pairs merged in registers: everything above);
+//        6 = the "petit-cdna4-nv6/1" image of NVFP4 weights (nvnative.hip: e2m3 elements + one E8M0 scale per 32 k, re-encoded ONCE at load
+//        time, stored in the instruction's own 32-row operand geometry): three 16-byte loads per lane, n32-block and k-tile, no merge, no
+//        unpack; the instruction runs at the rate of the ACTIVATION format (FP6 x FP6 / FP4 at the FP4 rate, x FP8 at the FP8 rate).
+template <class AT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int ACT_, int KT_ = 1, int PF_ = 1, int WM_ = 1, int KG_ = 1, int LW_ = 0, int WF_ = 4>
 struct Native32Cfg {
     using AT = AT_;
+    static constexpr int WF = WF_;
+    static constexpr int kWLoads = WF_ == 6 ? 3 : 2;              // 16-byte loads per lane, n32-block and k-tile
+    static_assert(WF_ == 4 || WF_ == 6, "weights: raw MXFP4 or the NV6 image");
 #ifndef PETIT_N32_LWPF
 #define PETIT_N32_LWPF 0
 #endif
@@ -369,7 +376,7 @@ struct Native32Cfg {
 #endif
     // PW (experiment, with LW): a PREFETCH wave that touches the workgroup's weight lines PETIT_N32_PW k-tiles ahead (one dword per 128-byte line, into
     // an LDS dump slot), so that the compute waves' refills find them in L2
-    static constexpr int PW = (LW_ && PETIT_N32_PW) ? 1 : 0;
+    static constexpr int PW = (LW_ && PETIT_N32_PW && WF_ == 4) ? 1 : 0;
     static constexpr int kThreads = kComputeThreads + 64 * (LW + PW);
     static_assert(KG == 1 || (KG == 2 && WM == 1), "two K groups only with one wave along M");
     static_assert(LW == 0 || (LW == 1 && KG == 1 && WM == 1 && PF_ >= 2), "the loader wave: one K group, stages in flight across the barrier");
@@ -417,12 +424,12 @@ struct Native32Cfg {
 
 // W refills (wave-loads) the stage that starts at tile t_first of a span issues: the tiles whose slot is needed again
 // (t_first < 0: a stage of the PREVIOUS span, which is never a last span: every tile is refilled)
-constexpr int n32_stage_refills(bool last_span, int t_first, int kt, int d, int ks, int np) {
+constexpr int n32_stage_refills(bool last_span, int t_first, int kt, int d, int ks, int np, int wloads = 2) {
     if (t_first < 0)
-        return 2 * np * kt;
+        return wloads * np * kt;
     int n = 0;
     for (int t = t_first; t < t_first + kt; ++t)
-        n += (!last_span || t + d < ks) ? 2 * np : 0;
+        n += (!last_span || t + d < ks) ? wloads * np : 0;
     return n;
 }
 
@@ -436,6 +443,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     constexpr unsigned kOob = 0x80000000u;
     constexpr int kFragU4 = ACT == 4 ? 1 : 2; // 16-byte units of one activation operand (FP6: registers 0-3, and the unit that holds 4-5 of P1 and P2)
     constexpr int kBlgp = ACT == 8 ? 0 : ACT == 6 ? 2 : 4; // the activation operand's format: e4m3 / e2m3 / e2m1
+    constexpr int WF = Cfg::WF, kWL = Cfg::kWLoads;
+    constexpr int kCbsz = WF == 6 ? 2 : 4;                  // the weight operand's format: e2m3 (the NV6 image) / e2m1 (raw MXFP4)
 
     // NBUF stages of [KT tile images][KT scale arrays]
     __shared__ u32x4 smem[Cfg::kSmemU4];
@@ -481,15 +490,40 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     const unsigned rows = min(p.m - m0, (unsigned)Cfg::BM);
     const unsigned pt0 = valid_nt ? physical_tile(nt0, ntiles, p.act) : 0u;
     const unsigned span_tiles = !valid_nt ? 0u : p.act ? (valid_nt >> 1) + (ntiles >> 1) : valid_nt;
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
-    const __amdgpu_buffer_rsrc_t s_rsrc = make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
-    unsigned w_voff[2 * NP], s_voff[2 * NP];
+    // WF = 6 (layout.h, "petit-cdna4-nv6/1"): the image is addressed from its start -- elements [N/32][K/128][3 planes][64 lanes] x 16 B, scales
+    // [N/32][K/(128 KS)][64 lanes][2][KS] bytes -- and every LANE finds its own weight row: lane (row = l % 32, h = l / 32) of n32-block np is
+    // row row % 16 of the logical n-tile nt0 + 2 np + row / 16, whose physical tile (SiLU-mul: a gate tile for rows 0-15, the matching up tile for
+    // 16-31) is one HALF of an image block.  The operand a wave ends up with is what merge_tiles builds for the raw layout, so both epilogues
+    // and the quantising SiLU-mul epilogue are shared.
+    const __amdgpu_buffer_rsrc_t w_rsrc = WF == 6 ? make_rsrc(p.w, (unsigned)nv6_elem_bytes(p.n, p.k))
+                                                  : make_rsrc((const char *)p.w + (size_t)pt0 * w_row_bytes, span_tiles * w_row_bytes);
+    const __amdgpu_buffer_rsrc_t s_rsrc = WF == 6 ? make_rsrc(p.s, (unsigned)nv6_scale_bytes(p.n, p.k))
+                                                  : make_rsrc((const char *)p.s + (size_t)pt0 * s_row_bytes, span_tiles * s_row_bytes);
+    unsigned w_voff[2 * NP], s_voff[2 * NP]; // (WF = 6: one entry per n32-block, [np])
+    if constexpr (WF == 6) {
 #pragma unroll
-    for (int nt = 0; nt < 2 * NP; ++nt) {
-        const unsigned rel = physical_tile(nt0 + nt, ntiles, p.act) - pt0;
-        w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
-        s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
+        for (int np = 0; np < NP; ++np) {
+            const unsigned nt = 2 * np + (m_l >> 4);
+            const unsigned pt = physical_tile(nt0 + nt, ntiles, p.act);
+            const unsigned lane_img = h * 32 + (pt & 1u) * 16 + (m_l & 15u);
+            w_voff[np] = nt < valid_nt ? (pt >> 1) * (ktiles * kNv6TileBytes) + lane_img * 16 : kOob;
+            s_voff[np] = nt < valid_nt ? (pt >> 1) * (ktiles * 128u) + lane_img * (2 * KS) : kOob;
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 2 * NP; ++nt) {
+            const unsigned rel = physical_tile(nt0 + nt, ntiles, p.act) - pt0;
+            w_voff[nt] = ((unsigned)nt < valid_nt) ? lane * 16 + rel * w_row_bytes : kOob;
+            s_voff[nt] = ((unsigned)nt < valid_nt) ? lane * kRecBytes + rel * s_row_bytes : kOob;
+        }
     }
+    // the 16-byte weight loads of k-tile kt: raw layout -- the two n-tiles of every pair; NV6 image -- planes P1 / P2 / tails of every n32-block
+    auto w_load = [&](int i, unsigned kt) -> u32x4 {
+        if constexpr (WF == 6)
+            return buf_load16(w_rsrc, w_voff[i / 3], kt * kNv6TileBytes + (i % 3) * 1024u, kAuxDefault);
+        else
+            return buf_load16(w_rsrc, w_voff[i], kt * kTileBytes, kAuxDefault);
+    };
     // quantised activations and their scales, k-tile major (see the layout note above): tile kt of this m-block starts at
     // (kt M + m0) rows of 16 ACT (data) / 4 (scales) bytes; the descriptors end with the data / scale region
     constexpr unsigned kRowB = 16 * Cfg::kRowU4;
@@ -682,6 +716,20 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
     }
     ScaleRec<kFmtMx, KS> rec[NP][2], rec_next[NP][2];
     auto load_recs = [&](ScaleRec<kFmtMx, KS> (*dst)[2], unsigned sp) {
+        if constexpr (WF == 6) { // the lane's record: [P1: KS bytes][P2: KS bytes]
+#pragma unroll
+            for (int np = 0; np < NP; ++np) {
+                const ScaleRec<kFmtNv, KS> x = load_scale_rec<kFmtNv, KS>(s_rsrc, s_voff[np], sp * 64 * (2 * KS));
+                if constexpr (KS == 2) {
+                    dst[np][0].d[0] = x.d[0] & 0xffffu, dst[np][1].d[0] = x.d[0] >> 16;
+                } else {
+#pragma unroll
+                    for (int d = 0; d < kRecDw; ++d)
+                        dst[np][0].d[d] = x.d[d], dst[np][1].d[d] = x.d[kRecDw + d];
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             const ScaleRec<kFmtMx, KS> x = load_scale_rec<kFmtMx, KS>(s_rsrc, s_voff[2 * np], sp * 64 * kRecBytes);
@@ -692,12 +740,12 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
         }
     };
     load_recs(rec, sp_begin);
-    u32x4 wring[D][2 * NP];
+    u32x4 wring[D][kWL * NP];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
-        for (int nt = 0; nt < 2 * NP; ++nt)
-            wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxDefault);
+        for (int nt = 0; nt < kWL * NP; ++nt)
+            wring[i][nt] = w_load(nt, kt_begin + i);
     __syncthreads(); // (drains everything once: stage 0 is complete and visible)
 
     unsigned cur_buf = 0; // stage index of the current k-tiles, rotates with period NBUF (wave-uniform)
@@ -740,21 +788,33 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                 i32x8 wop[NP][2];
 #pragma unroll
                 for (int np = 0; np < NP; ++np) {
-                    unsigned pw[2][4];
+                    if constexpr (WF == 6) { // registers 0-3 of P1 / P2 as loaded; 4-5 from the shared tail plane
+                        const u32x4 l1 = wring[SLOT][3 * np], l2 = wring[SLOT][3 * np + 1], tl = wring[SLOT][3 * np + 2];
+                        wop[np][0] = i32x8{(int)l1[0], (int)l1[1], (int)l1[2], (int)l1[3], (int)tl[0], (int)tl[1], 0, 0};
+                        wop[np][1] = i32x8{(int)l2[0], (int)l2[1], (int)l2[2], (int)l2[3], (int)tl[2], (int)tl[3], 0, 0};
+                    } else {
+                        unsigned pw[2][4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        merge_tiles(wring[SLOT][2 * np][j], wring[SLOT][2 * np + 1][j], pw[0][j], pw[1][j]);
+                        for (int j = 0; j < 4; ++j)
+                            merge_tiles(wring[SLOT][2 * np][j], wring[SLOT][2 * np + 1][j], pw[0][j], pw[1][j]);
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
-                        wop[np][q] = i32x8{(int)pw[q][0], (int)pw[q][1], (int)pw[q][2], (int)pw[q][3], 0, 0, 0, 0};
+                        for (int q = 0; q < 2; ++q)
+                            wop[np][q] = i32x8{(int)pw[q][0], (int)pw[q][1], (int)pw[q][2], (int)pw[q][3], 0, 0, 0, 0};
+                    }
                 }
-                if constexpr (kRefill && !(PETIT_ABLATE_N32 & 2)) {
-                    // the merged operands are copies: the ring slot is free as soon as they exist, and its refill goes out BEFORE the tile's MFMAs
-                    // (requests spread over the stage instead of a burst behind the barrier: -2...6 % at M = 512, profiles/r03_native_ablation.md)
+                // raw layout: the merged operands are copies: the ring slot is free as soon as they exist, and its refill goes out BEFORE the tile's MFMAs
+                // (requests spread over the stage instead of a burst behind the barrier: -2...6 % at M = 512, profiles/r03_native_ablation.md).
+                // NV6 image: the ring registers ARE the operands (a refill ahead of the MFMAs would need 12 more registers per n32-block: the
+                // 128 x 256 forms then spill 100-450 registers at two waves per SIMD), so the slot is refilled right after its last MFMA is issued.
+                auto refill_slot = [&]() {
+                    if constexpr (kRefill && !(PETIT_ABLATE_N32 & 2)) {
 #pragma unroll
-                    for (int nt = 0; nt < 2 * NP; ++nt)
-                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt0 + T + D) * kTileBytes, kAuxDefault);
-                }
+                        for (int nt = 0; nt < kWL * NP; ++nt)
+                            wring[SLOT][nt] = w_load(nt, kt0 + T + D);
+                    }
+                };
+                if constexpr (WF != 6)
+                    refill_slot();
                 static_for<0, 2>([&](auto q_c) {
                     constexpr int q = decltype(q_c)::value, gi = 2 * TI + q; // group index inside the stage
                     if constexpr (Cfg::kLean) {
@@ -779,7 +839,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                             }
 #pragma unroll
                             for (int np = 0; np < NP; ++np)
-                                acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, kBlgp /* B = FP8 e4m3 / FP6 e2m3 */,
+                                acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wop[np][q], aop, acc[mb][np], kCbsz /* A = FP4 / FP6 */, kBlgp /* B = FP8 e4m3 / FP6 e2m3 */,
                                                                                               T % 4, (int)rec[np][q].d[T / 4], 0, f1[li & 1].s);
                         });
                     }
@@ -815,13 +875,17 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
 #endif
                             } else {
                                 acc[mb][np] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                                    wop[np][q], aop, acc[mb][np], 4 /* A = FP4 */, kBlgp /* B = FP8 e4m3 / FP6 e2m3 / FP4 */, T % 4,
+                                    wop[np][q], aop, acc[mb][np], kCbsz /* A = FP4 / FP6 */, kBlgp /* B = FP8 e4m3 / FP6 e2m3 / FP4 */, T % 4,
                                     (int)rec[np][q].d[T / 4], 0, fr[fi].s[mb]);
                             }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
+                if constexpr (WF == 6) {
+                    refill_slot();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 (void)a_cur, (void)sc_cur, (void)refills;
             });
             if constexpr (PF == 1) {
@@ -839,8 +903,8 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_nat
                     constexpr int kPrevRefills = [] {
                         int n = 0;
                         for (int j = 1; j < PF; ++j) // (the refills of the PF - 1 stages before this one)
-                            n += n32_stage_refills(kLast, T0 - j * KT, KT, D, KS, NP);
-                        n += n32_stage_refills(kLast, T0, KT, D, KS, NP); // (this stage's refills are already in the queue)
+                            n += n32_stage_refills(kLast, T0 - j * KT, KT, D, KS, NP, Cfg::kWLoads);
+                        n += n32_stage_refills(kLast, T0, KT, D, KS, NP, Cfg::kWLoads); // (this stage's refills are already in the queue)
                         return (PETIT_ABLATE_N32 & 2) ? 0 : n;
                     }();
 #if defined(__HIP_DEVICE_COMPILE__)

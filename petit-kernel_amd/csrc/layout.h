@@ -95,4 +95,31 @@ PETIT_HD size_t packed_mxscale_byte_index(unsigned k_total, unsigned n, unsigned
     return rec * ks + t;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// "petit-cdna4-nv6/1": the MFMA-native image of NVFP4 weights (nvnative.hip builds it ONCE at load time; gemm_native32.hpp, WF = 6,
+// consumes it).  NVFP4's e4m3 group-16 scales do not fit the block-scaled MFMA (one E8M0 scale per 32 k), so every 32-k block of a
+// weight row is re-encoded:  E = floor(log2(max |fp4 x scale| of the block)) - 2,  element = RNE_e2m3(fp4 x scale / 2^E)  (FP6 e2m3:
+// the block maximum lands in [4, 7.5]; never saturates, see nvnative.hip), scale byte = E + 127.  A different ACCURACY CLASS
+// (petit_amd.h "Native-FP4 kernels"): 4-significant-bit elements where fp4 x e4m3 has up to 6.
+//   elements : u8 img[N32][K/128][3][64][16]      N32 = ceil(N / 32) blocks of 32 weight rows (rows >= N: zeros)
+//              the instruction's own operand geometry -- lane l = 32 h + r of block (b, kt) holds row 32 b + r;
+//              plane 0: registers 0-3 of operand P1 (k = 128 kt + 32 h + e, e = 0 .. 31: element e at bits [6 e, 6 e + 6) of the lane's 192);
+//              plane 1: registers 0-3 of operand P2 (k = 128 kt + 64 + 32 h + e);  plane 2: {P1 reg 4, P1 reg 5, P2 reg 4, P2 reg 5}.
+//              6 bits per weight: 3 KiB per (block, k-tile), one contiguous stream per block along K.
+//   scales   : u8 sc[N32][K/(128 KS)][64][2][KS]   lane (r, h): [q][t] = E8M0 byte of block (k / 32) = 4 (KS sp + t) + 2 q + h
+constexpr unsigned kNv6TileBytes = 3072;
+PETIT_HD size_t nv6_elem_bytes(unsigned n, unsigned k) { return (size_t)((n + 31) / 32) * (k / kTileK) * kNv6TileBytes; }
+PETIT_HD size_t nv6_scale_bytes(unsigned n, unsigned k) { return (size_t)((n + 31) / 32) * (k / kTileK) * 128; }
+PETIT_HD size_t nv6_image_bytes(unsigned n, unsigned k) { return nv6_elem_bytes(n, k) + nv6_scale_bytes(n, k); }
+// byte offset (inside the element part) of the 16-byte unit `plane` of lane (row n % 32, h) of k-tile kt
+PETIT_HD size_t nv6_unit_offset(unsigned k_total, unsigned n, unsigned kt, unsigned plane, unsigned h) {
+    return ((size_t)(n / 32) * (k_total / kTileK) + kt) * kNv6TileBytes + plane * 1024 + (h * 32 + n % 32) * 16;
+}
+// byte offset (inside the scale part) of the E8M0 byte of 32-k block blk of row n
+PETIT_HD size_t nv6_scale_offset(unsigned k_total, unsigned n, unsigned blk) {
+    const unsigned ks = (unsigned)span_tiles_for_k(k_total);
+    const unsigned kt = blk / 4, q = (blk % 4) / 2, h = blk % 2, sp = kt / ks, t = kt % ks;
+    return (((size_t)(n / 32) * (k_total / (kTileK * ks)) + sp) * 64 + (h * 32 + n % 32)) * (2 * ks) + q * ks + t;
+}
+
 } // namespace petit_amd

@@ -88,6 +88,7 @@ namespace petit_amd {
 // out_format 8 / 4 = the SiLU-mul epilogue emits quantised activations instead of a 16-bit matrix
 struct NativeIo {
     unsigned a_format, out_format;
+    const void *image = nullptr; // NVFP4 weights: their MFMA-native image (nvnative.hip), when the caller hands it over per call
 };
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales, const float *global_scale, unsigned m,
               unsigned n, unsigned k, const petit_solution_hints *hints, uint64_t solution_id, const petit_epilogue *epilogue, void *call_ws,
@@ -131,6 +132,10 @@ int repack_mxscales_host(void *out, const void *in, unsigned k, unsigned n);
 int convert_reference_weights_host(void *out, const void *in, unsigned k, unsigned n);
 int convert_reference_nvscales_host(void *out, const void *in, unsigned k, unsigned n);
 int convert_reference_mxscales_host(void *out, const void *in, unsigned k, unsigned n);
+// nvnative.hip: the MFMA-native image of NVFP4 weights ("petit-cdna4-nv6/1", layout.h) from the packed tensors; host twin; dense expansion (host)
+int nv6_image(void *image, const void *pw, const void *ps, unsigned n, unsigned k, hipStream_t stream);
+int nv6_image_host(void *image, const void *pw, const void *ps, unsigned n, unsigned k);
+int nv6_image_dequant_host(float *out, const void *image, unsigned n, unsigned k);
 // dequant.hip: dense expansion of packed weights (debug aid); out_kind 0 f32, 1 bf16, 2 fp16
 int dequant_packed(void *out, const void *w, const void *s, float gs, unsigned n, unsigned k, int b_type, int out_kind, hipStream_t stream);
 

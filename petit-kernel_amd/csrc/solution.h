@@ -137,6 +137,8 @@ const SolutionEntry *solutions_nv_f16_p6(int *);
 const SolutionEntry *solutions_mx_bf16_p6(int *);
 const SolutionEntry *solutions_mx_bf16_p5(int *); // native FP4 MFMA kernels: MXFP4 weights only
 const SolutionEntry *solutions_mx_f16_p5(int *);
+const SolutionEntry *solutions_nv_bf16_p5(int *); // the same kernels on the MFMA-native image of NVFP4 weights (nvnative.hip)
+const SolutionEntry *solutions_nv_f16_p5(int *);
 // the activation quantiser of the 32x32x64 native kernels, stand-alone (gemm_mx_{bf16,f16}.hip): format 8 = MXFP8, 4 = MXFP4
 int quantize32_bf16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);
 int quantize32_f16(const void *a, void *qa, unsigned m, unsigned k, int format, hipStream_t stream);

@@ -105,7 +105,10 @@ at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::
     // signed int64 -- such an id arrives as its two's-complement value (petit_kernel/compiled.py maps it) and is
     // reinterpreted here.  A small negative value is "library default", as in the reference (fp4.cc:189-191,240: solution_id < 0) -- including
     // -2 / -3, which name the native class only on ITS entry point (mul_mxfp4_native): these two ops are the reference's, and exact
-    const uint64_t sid = (solution_id < 0 && solution_id >= -4096) ? PETIT_SOLUTION_AUTO : (uint64_t)solution_id;
+    uint64_t sid = (solution_id < 0 && solution_id >= -4096) ? PETIT_SOLUTION_AUTO : (uint64_t)solution_id;
+    // NVFP4 weights with an MFMA-native image attached (petit_nvfp4_native_attach) have opted into the native class: -2 / -3 / -4 name it then
+    if (!mx && solution_id <= -2 && solution_id >= -4 && petit_nvfp4_native_attached(B.data_ptr()))
+        sid = solution_id == -2 ? PETIT_SOLUTION_AUTO_NATIVE_MXFP8 : solution_id == -3 ? PETIT_SOLUTION_AUTO_NATIVE_MXFP4 : PETIT_SOLUTION_AUTO_NATIVE_MXFP6;
     const petit_epilogue epi{bias.has_value() ? bias->data_ptr() : nullptr, (int32_t)activation, 0};
     // per-call scratch from the caching allocator (stream-ordered, capture-safe): K-split slabs / native-FP4 activations
     const uint64_t ws_bytes = petit_gemm_workspace_bytes_ex(&hints, (unsigned)size_m, (unsigned)size_n, (unsigned)size_k, sid,
@@ -118,7 +121,7 @@ at::Tensor mul_a16(bool mx, const at::Tensor &A, const at::Tensor &B, const at::
                       (const float *)global_scale.data_ptr(), (unsigned)size_m, (unsigned)size_n, (unsigned)size_k, &hints, sid,
                       (bias.has_value() || activation) ? &epi : nullptr, ws_bytes ? ws.data_ptr() : nullptr, ws_bytes, stream_of(A));
     TORCH_CHECK(rc != PETIT_ERROR_PROBLEM_SHAPE, "Incompatible problem shape (m=", size_m, ", n=", size_n, ", k=", size_k, ")");
-    TORCH_CHECK(rc != PETIT_ERROR_KERNEL_SHAPE, "No kernel implementation for solution_id=", sid == PETIT_SOLUTION_AUTO ? "-1" : std::to_string(sid), ".");
+    TORCH_CHECK(rc != PETIT_ERROR_KERNEL_SHAPE, "No kernel implementation for solution_id=", sid == PETIT_SOLUTION_AUTO ? "-1" : std::to_string((int64_t)sid), ".");
     TORCH_CHECK(rc == PETIT_OK, mx ? "mul_mxfp4_a16: " : "mul_nvfp4_a16: ", petit_error_string(rc));
     return c;
 }

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/petit_amd.h"
+#include "layout.h"
 #include "hal.h"
 #include "petit_internal.h"
 
@@ -246,11 +247,24 @@ int tune_problem(const TuneRequest &rq, uint64_t *best_solution, float *best_us)
         }
     }
     const size_t copies = wb.size();
+    // the native class on NVFP4 weights runs on the weights' MFMA-native image (nvnative.hip): one per copy of the rotation, built here
+    std::vector<const void *> images;
+    if (rq.klass != 0 && rq.b_type == kDataTypeFp4e2m1) {
+        const size_t img_bytes = nv6_image_bytes(rq.n, rq.k);
+        for (size_t i = 0; i < copies; ++i) {
+            void *img = mem.alloc(img_bytes);
+            if (!img || nv6_image(img, wb[i], ws_[i], rq.n, rq.k, stream) != kOk)
+                return kErrLaunch;
+            images.push_back(img);
+        }
+    }
 
     const petit_solution_hints hints{rq.a_type, rq.b_type, rq.a_type, 0};
     auto run = [&](uint64_t id, void *out, size_t copy) {
+        const NativeIo io{0u, 0u, images.empty() ? nullptr : images[copy % copies]};
         return gemm_impl(rq.b_type, (unsigned *)out, (const unsigned *)rq.a, (const unsigned *)wb[copy % copies],
-                         (const unsigned *)ws_[copy % copies], rq.gs, rq.m, rq.n, rq.k, &hints, id, nullptr, ws, ws_bytes, rq.stream);
+                         (const unsigned *)ws_[copy % copies], rq.gs, rq.m, rq.n, rq.k, &hints, id, nullptr, ws, ws_bytes, rq.stream,
+                         images.empty() ? nullptr : &io);
     };
     // reference output: candidate 0 (tune_candidates puts the class's reference kernel first), and its rms: the floor of the comparison
     float *stats = (float *)mem.alloc(2 * sizeof(float));

@@ -14,6 +14,7 @@ import torch
 
 from . import compiled, offline, ops, tuning
 from .ops import QuantizedActivations, mul_fp4_a16_grouped, mul_mxfp4_native, quantize_activations
+from .ops import attach_nvfp4_native, mul_nvfp4_native, nvfp4_native_image
 from .tuning import tune, tune_tensors
 from .ops import SOLUTION_AUTO, SOLUTION_AUTO_NATIVE_MXFP4, SOLUTION_AUTO_NATIVE_MXFP6, SOLUTION_AUTO_NATIVE_MXFP8, PetitSolutionHints
 from ._lib import MXFP4_F16RANGE_SCALE_MAX, MXFP4_F16RANGE_SCALE_MIN
@@ -109,6 +110,9 @@ __all__ = [
     "quantize_activations",
     "mul_fp4_a16_grouped",
     "mul_mxfp4_native",
+    "nvfp4_native_image",
+    "attach_nvfp4_native",
+    "mul_nvfp4_native",
     "QuantizedActivations",
     "SOLUTION_AUTO",
     "SOLUTION_AUTO_NATIVE_MXFP8",

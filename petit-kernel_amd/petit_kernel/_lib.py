@@ -104,6 +104,14 @@ _SIGNATURES = {
                                               C.c_void_p]),
     "petit_gemm_mxfp4_native": (C.c_int, [C.c_void_p] * 5 + [C.c_uint] * 3 + [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue),
                                           C.POINTER(NativeArgs), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "petit_nvfp4_native_image_bytes": (C.c_uint64, [C.c_uint, C.c_uint]),
+    "petit_nvfp4_native_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
+    "petit_nvfp4_native_image_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_nvfp4_native_image_dequant_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint]),
+    "petit_nvfp4_native_attach": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "petit_nvfp4_native_attached": (C.c_void_p, [C.c_void_p]),
+    "petit_gemm_nvfp4_native": (C.c_int, [C.c_void_p] * 4 + [C.c_uint] * 3 + [C.POINTER(SolutionHints), C.c_uint64, C.POINTER(Epilogue),
+                                          C.POINTER(NativeArgs), C.c_void_p, C.c_uint64, C.c_void_p]),
     "petit_gemm_native_workspace_bytes": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Epilogue),
                                                        C.POINTER(NativeArgs)]),
     "petit_quantized_activation_bytes": (C.c_uint64, [C.c_uint, C.c_uint, C.c_int]),

@@ -98,3 +98,29 @@ def from_reference_packed_mxfp4_scales(s_packed: torch.Tensor, size_n: int, size
     _raise_on(_lib.lib.petit_convert_reference_mxfp4_scales_host(out.data_ptr(), s_packed.contiguous().data_ptr(), size_k, size_n),
               "from_reference_packed_mxfp4_scales")
     return out
+
+
+# --- the MFMA-native image of NVFP4 weights, offline (include/petit_amd.h "NVFP4 weights on the native class") ---------------------------
+
+def nvfp4_native_image_cpu(b_packed: torch.Tensor, s_packed: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """CPU twin of petit_kernel.nvfp4_native_image: the PACKED tensors (repack_nvfp4_cpu / process_nvfp4_scales_cpu) -> the image, uint8, bit-identical
+    to what the device kernel builds; save it with the checkpoint and copy it to the GPU as it is."""
+    nbytes = int(_lib.lib.petit_nvfp4_native_image_bytes(size_k, size_n))
+    _check(nbytes > 0, f"Incompatible problem shape (n={size_n}, k={size_k})")
+    _check(b_packed.numel() * b_packed.element_size() == size_n * size_k // 2, "b_packed does not hold size_n * size_k 4-bit weights")
+    _check(s_packed.numel() * s_packed.element_size() == size_n * size_k // 16, "s_packed does not hold size_n * size_k / 16 scales")
+    _cpu(b_packed, "b_packed")
+    _cpu(s_packed, "s_packed")
+    image = torch.empty(nbytes, dtype=torch.uint8)
+    _raise_on(_lib.lib.petit_nvfp4_native_image_host(image.data_ptr(), b_packed.data_ptr(), s_packed.data_ptr(), size_k, size_n), "nvfp4_native_image_cpu")
+    return image
+
+
+def nvfp4_native_image_dequant_cpu(image: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """Dense expansion of an image on the CPU (test / debug aid): f32 [N, K] = element x 2^(scale - 127), WITHOUT the global scale."""
+    _check(image.dtype == torch.uint8 and image.numel() == int(_lib.lib.petit_nvfp4_native_image_bytes(size_k, size_n)) and image.numel() > 0,
+           "image does not hold the native image of size_n x size_k NVFP4 weights")
+    _cpu(image, "image")
+    out = torch.empty((size_n, size_k), dtype=torch.float32)
+    _raise_on(_lib.lib.petit_nvfp4_native_image_dequant_host(out.data_ptr(), image.data_ptr(), size_k, size_n), "nvfp4_native_image_dequant_cpu")
+    return out

@@ -202,7 +202,8 @@ def _mul(kind: str, A, B, s, global_scale, size_m, size_n, size_k, solution_id, 
     # require_high_precision: the reference turns it on for arch <= gfx90a when
     # solution_id < 0 (fp4.cc:24-34,189-191); gfx950 -> False.
     hints = _CHints(a_type, b_type, a_type, 0)
-    sid = _c_solution_id(solution_id)
+    # (NVFP4 weights with an MFMA-native image attached -- attach_nvfp4_native -- have opted into the native class: -2 / -3 / -4 then name it)
+    sid = _c_solution_id(solution_id, native_ok=(kind == "nv" and int(solution_id) in (-2, -3, -4) and B.data_ptr() in _attached_images))
     epi = None
     if bias is not None or act:
         # fused epilogue (include/petit_amd.h, petit_epilogue): c = round16(act(acc * gs + bias[n]))
@@ -458,6 +459,93 @@ def mul_mxfp4_native(A, B, s, global_scale, size_m, size_n, size_k, solution_id=
     if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
         raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
     _raise_on(err, "mul_mxfp4_native")
+    return QuantizedActivations(c, size_m, size_n // 2, out_quantized, dtype) if out_fmt else c
+
+
+# --- NVFP4 weights on the native class (include/petit_amd.h "NVFP4 weights on the native class"; no counterpart in the reference) ----------
+
+_attached_images = {}   # data_ptr of the packed weights -> the image tensor (kept alive for as long as it is attached)
+
+
+def nvfp4_native_image(B: torch.Tensor, s: torch.Tensor, size_n: int, size_k: int) -> torch.Tensor:
+    """The MFMA-native image ("petit-cdna4-nv6/1": FP6 e2m3 elements + one E8M0 scale per 32 k, 6.25 bits per weight) of NVFP4 weights,
+    from the PACKED tensors of repack_nvfp4 / process_nvfp4_scales; one launch, once at load time.  An opaque uint8 tensor."""
+    _check(B.is_cuda and s.is_cuda and B.device == s.device, "B and s must be GPU tensors on one device")
+    _check(B.is_contiguous() and B.numel() * B.element_size() == size_n * size_k // 2, "B does not hold size_n * size_k packed 4-bit weights")
+    _check(s.is_contiguous() and s.numel() * s.element_size() == size_n * size_k // 16, "s does not hold size_n * size_k / 16 scales")
+    nbytes = int(_lib.lib.petit_nvfp4_native_image_bytes(size_k, size_n))
+    if nbytes == 0:
+        raise RuntimeError(f"Incompatible problem shape (n={size_n}, k={size_k})")
+    image = torch.empty(nbytes, dtype=torch.uint8, device=B.device)
+    with torch.cuda.device(B.device):
+        rc = _lib.lib.petit_nvfp4_native_image(_ptr(image), _ptr(B), _ptr(s), size_k, size_n, _stream(B))
+    if rc == _lib.PETIT_ERROR_PROBLEM_SHAPE:
+        raise RuntimeError(f"Incompatible problem shape (n={size_n}, k={size_k})")
+    _raise_on(rc, "nvfp4_native_image")
+    return image
+
+
+def attach_nvfp4_native(B: torch.Tensor, image) -> None:
+    """Attach `image` (nvfp4_native_image) to the packed weights B: mul_nvfp4_a16(..., B, ..., solution_id = -2 / -3 / -4) then runs the native
+    class on it (MXFP8 / MXFP4 / MXFP6 activations).  image = None detaches.  The image is kept alive while attached; detach before B is freed."""
+    key = B.data_ptr()
+    if image is None:
+        _attached_images.pop(key, None)
+        _raise_on(_lib.lib.petit_nvfp4_native_attach(C.c_void_p(key), None), "attach_nvfp4_native")
+        return
+    _check(image.is_cuda and image.device == B.device and image.dtype == torch.uint8 and image.is_contiguous(), "image must come from nvfp4_native_image")
+    _raise_on(_lib.lib.petit_nvfp4_native_attach(C.c_void_p(key), _ptr(image)), "attach_nvfp4_native")
+    _attached_images[key] = image
+
+
+def mul_nvfp4_native(A, image: torch.Tensor, global_scale, size_m, size_n, size_k, solution_id=SOLUTION_AUTO_NATIVE_MXFP8, bias=None,
+                     activation=None, out_quantized=None):
+    """NVFP4 weights on the block-scaled MFMA (petit_gemm_nvfp4_native): `image` from nvfp4_native_image; everything else as mul_mxfp4_native
+    (A a 16-bit tensor or QuantizedActivations; solution_id -2 / -3 / -4 = MXFP8 / MXFP4 / MXFP6 activations or an explicit native id of the
+    NVFP4 family; out_quantized with activation='silu_mul')."""
+    pre = isinstance(A, QuantizedActivations)
+    if pre:
+        _check(A.m == size_m and A.k == size_k, f"quantised activations are [{A.m}, {A.k}], the call says [{size_m}, {size_k}]")
+        a_t, dtype, a_fmt, dev = A.data, A.dtype, _QFORMATS[A.fmt], A.data.device
+    else:
+        _check(A.is_cuda and A.is_contiguous() and A.numel() == size_m * size_k and A.dtype in (torch.bfloat16, torch.float16),
+               "A must be a contiguous [size_m, size_k] bfloat16 / float16 GPU tensor")
+        a_t, dtype, a_fmt, dev = A, A.dtype, 0, A.device
+    _check(image.is_cuda and global_scale.is_cuda, "all tensors must be on GPU")
+    _check(image.is_contiguous() and image.dtype == torch.uint8 and
+           image.numel() == int(_lib.lib.petit_nvfp4_native_image_bytes(size_k, size_n)) and image.numel() > 0,
+           "image does not hold the native image of size_n x size_k NVFP4 weights")
+    _check(activation in _ACTIVATIONS, f"activation must be one of {sorted(k for k in _ACTIVATIONS if k)} or None")
+    _check(out_quantized is None or out_quantized in _QFORMATS, "out_quantized must be None, 'mxfp8', 'mxfp6' or 'mxfp4'")
+    act = _ACTIVATIONS[activation]
+    out_fmt = _QFORMATS[out_quantized] if out_quantized else 0
+    _check(not out_fmt or act, "out_quantized needs activation='silu_mul'")
+    a_type = _lib.CXX_DTYPE_BF16 if dtype == torch.bfloat16 else _lib.CXX_DTYPE_FP16
+    hints = _CHints(a_type, _lib.CXX_DTYPE_FP4_E2M1, a_type, 0)
+    sid = _c_solution_id(solution_id, native_ok=True)
+    epi = None
+    if bias is not None or act:
+        if bias is not None:
+            _check(bias.is_cuda and bias.device == dev and bias.dtype == dtype and bias.is_contiguous() and bias.numel() == size_n,
+                   "bias must be a contiguous [size_n] tensor of the activation dtype on the same device")
+        epi = _lib.Epilogue(bias.data_ptr() if bias is not None else None, act, 0)
+    na = _lib.NativeArgs(C.sizeof(_lib.NativeArgs), a_fmt, out_fmt, 0)
+    epi_p = C.byref(epi) if epi is not None else None
+    if out_fmt:
+        c = torch.empty(int(_lib.lib.petit_quantized_activation_bytes(size_m, size_n // 2, out_fmt)), dtype=torch.uint8, device=dev)
+    else:
+        c = torch.empty((size_m, size_n // 2 if act else size_n), dtype=dtype, device=dev)
+    ws_bytes = int(_lib.lib.petit_gemm_native_workspace_bytes(C.byref(hints), size_m, size_n, size_k, C.c_uint64(sid), epi_p, C.byref(na)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+    with torch.cuda.device(dev):
+        err = _lib.lib.petit_gemm_nvfp4_native(_ptr(c), _ptr(a_t), _ptr(image), _ptr(global_scale), size_m, size_n, size_k, C.byref(hints),
+                                               C.c_uint64(sid), epi_p, C.byref(na), _ptr(ws) if ws is not None else None, C.c_uint64(ws_bytes),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if err == _lib.PETIT_ERROR_PROBLEM_SHAPE:
+        raise RuntimeError(f"Incompatible problem shape (m={size_m}, n={size_n}, k={size_k})")
+    if err == _lib.PETIT_ERROR_KERNEL_SHAPE:
+        raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
+    _raise_on(err, "mul_nvfp4_native")
     return QuantizedActivations(c, size_m, size_n // 2, out_quantized, dtype) if out_fmt else c
 
 

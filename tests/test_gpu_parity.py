@@ -1125,6 +1125,24 @@ class FullSizeProblem:
         self.rows = np.unique(np.concatenate([rng.integers(0, n, 60), [0, 15, n - 16, n - 1]]))
         dq = O.dequant_nvfp4(self.q[self.rows], self.s[self.rows]) if kind == "nv" else O.dequant_mxfp4(self.q[self.rows], self.s[self.rows])
         self.dq = dq
+        self._image = None
+
+    @property
+    def image(self):
+        """NVFP4 weights on the native class: the MFMA-native image (built once, attached to the packed weights), and the sampled rows as the image
+        holds them (oracle.nv6_reencode) with the stated per-element re-rounding bound."""
+        if self._image is None:
+            assert self.kind == "nv"
+            self._image = self.pk.nvfp4_native_image(self.b, self.sp, self.n, self.k)
+            self.pk.attach_nvfp4_native(self.b, self._image)
+            self.dq_native, sb = O.nv6_reencode(self.q[self.rows], self.s[self.rows])
+            self.w_rebound = np.maximum(2.0 ** -4 * np.abs(self.dq), np.repeat(np.ldexp(1.0, sb.astype(np.int64) - 127 - 4), 32, axis=1))
+            assert (np.abs(self.dq_native - self.dq) <= self.w_rebound).all()
+        return self._image
+
+    def __del__(self):
+        if getattr(self, "_image", None) is not None:
+            self.pk.attach_nvfp4_native(self.b, None)
 
     def hints(self, is_bf16):
         h = self.pk.PetitSolutionHints()
@@ -1140,7 +1158,17 @@ class FullSizeProblem:
         dtype = torch.bfloat16 if is_bf16 else torch.float16
         m = a_bits.shape[0]
         # (the native-class sentinels name that class on its own entry point only; the reference's entry points read any negative id as -1)
-        mul = self.pk.mul_mxfp4_native if sid in (self.pk.SOLUTION_AUTO_NATIVE_MXFP8, self.pk.SOLUTION_AUTO_NATIVE_MXFP6, self.pk.SOLUTION_AUTO_NATIVE_MXFP4) else self.mul
+        sentinel = sid in (self.pk.SOLUTION_AUTO_NATIVE_MXFP8, self.pk.SOLUTION_AUTO_NATIVE_MXFP6, self.pk.SOLUTION_AUTO_NATIVE_MXFP4)
+        if self.kind == "nv" and (sentinel or (sid > 0 and (sid >> 48) & 0xF == 13)):
+            # NVFP4 weights on the native class: sentinels through the reference's entry point (the image is attached), explicit ids through the class's own
+            _ = self.image
+            if sentinel:
+                c = self.mul(from_bits(a_bits, dtype).to(DEV), self.b, self.sp, self.gsd, m, self.n, self.k, sid)
+            else:
+                c = self.pk.mul_nvfp4_native(from_bits(a_bits, dtype).to(DEV), self.image, self.gsd, m, self.n, self.k, sid)
+            torch.cuda.synchronize()
+            return c
+        mul = self.pk.mul_mxfp4_native if sentinel else self.mul
         c = mul(from_bits(a_bits, dtype).to(DEV), self.b, self.sp, self.gsd, m, self.n, self.k, sid)
         torch.cuda.synchronize()
         return c
@@ -1262,9 +1290,17 @@ def check_native_sampled(P, c, a_bits, act_code, tag):
     if key not in cache:
         a_f32 = to_f32(a_bits, True)
         a_q = {2: quantize_act_mxfp8, 4: quantize_act_mxfp6, 6: quantize_act_mxfp4}[act_code](a_f32)
-        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, P.dq, P.gs)
+        # NVFP4 weights run on their MFMA-native image: exact semantics on the image's values; against the unquantised oracle (the TRUE NVFP4 weights) the
+        # class tolerance widens by the stated re-rounding bound of the weights, sum_k |a_k| max(2^-4 |w_k|, 2^(E_k - 4))  (include/petit_amd.h)
+        if P.kind == "nv":
+            _ = P.image
+        dq_run = P.dq_native if P.kind == "nv" else P.dq
+        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq_run, P.gs)
         _, full = O.gemm_ref(a_bits, True, P.dq, P.gs)
-        cache[key] = (exact, full, (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs, native_exact_bound(a_q, P.dq, P.gs, {2: "mxfp8", 4: "mxfp6", 6: "mxfp4"}[act_code]))
+        sum_abs = (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs
+        if P.kind == "nv":
+            sum_abs = sum_abs + (np.abs(a_f32) @ P.w_rebound.T) * P.gs / {2: 2e-2, 4: 2e-2, 6: 0.12}[act_code]   # (enters as coef * sum_abs below)
+        cache[key] = (exact, full, sum_abs, native_exact_bound(a_q, dq_run, P.gs, {2: "mxfp8", 4: "mxfp6", 6: "mxfp4"}[act_code]))
     exact, full, sum_abs, derived = cache[key]
     got = to_f32(bits(c[:, torch.from_numpy(P.rows).to(DEV)]), True).astype(np.float64)
     err = np.abs(got - exact)
@@ -1309,9 +1345,22 @@ def test_m512_full_size_tiled_and_native(pk, kind, shape):
                 assert picked and (picked >> 48) & 0xF in (9, 13) and (picked >> 32) & 7 == code, hex(picked)
                 check_native_sampled(P, P.run(a, True, auto_sid), a, code, f"native default {auto_sid} -> {picked:#x}")
         else:
-            assert not native            # the native class exists for MXFP4 weights only
+            # NVFP4 weights (round 6): the same kernels on the MFMA-native image of the weights -- refused while no image is attached, then every
+            # enumerated kernel (K split 1 / 2) and the three sentinels through the reference's own entry point
+            assert {(sid >> 32) & 7 for sid in native} == {2, 4, 6} and all((sid >> 48) & 0xF == 13 and (sid >> 28) & 0xF == 1 for sid in native)
+            assert P._image is None
             with pytest.raises(RuntimeError):
-                P.run(a, True, pk.SOLUTION_AUTO_NATIVE_MXFP4)
+                pk.mul_nvfp4_a16(from_bits(a, torch.bfloat16).to(DEV), P.b, P.sp, P.gsd, m, n, k, native[0])
+            assert torch.equal(pk.mul_nvfp4_a16(from_bits(a, torch.bfloat16).to(DEV), P.b, P.sp, P.gsd, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP8),
+                               P.run(a, True))         # (no image attached: -2 reads as the library default, as in the reference)
+            for sid in native:
+                for splitk in (1, 2):
+                    sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                    check_native_sampled(P, P.run(a, True, sk), a, (sid >> 32) & 7, f"nv native {sk:#x}")
+            for auto_sid, code in ((pk.SOLUTION_AUTO_NATIVE_MXFP8, 2), (pk.SOLUTION_AUTO_NATIVE_MXFP6, 4), (pk.SOLUTION_AUTO_NATIVE_MXFP4, 6)):
+                picked = pk.ops.resolve_solution(P.hints(True), m, n, k, auto_sid)
+                assert picked and (picked >> 48) & 0xF == 13 and (picked >> 32) & 7 == code and (picked >> 28) & 0xF == 1, hex(picked)
+                check_native_sampled(P, P.run(a, True, auto_sid), a, code, f"nv native default {auto_sid} -> {picked:#x}")
     finally:
         pk.ops.enable_native_fp4(False)
 
@@ -1368,7 +1417,8 @@ def test_bench_cells_parity(pk):
     mid, pre = set(BL.MID_MS), set(BL.PREFILL_MS)
     assert mid == {32, 44, 64, 128} and pre == {1024, 2084, 4314, 16375}   # the reference's representative M list, tools/benchmarks/matmul.py:8-90
     assert {c["M"] for c in plan if (c["a"], c["w"], c["mode"]) == ("bf16", "mx", "auto")} == {1, 16, 512} | mid | pre   # the reference's only MX activation type
-    assert {c["M"] for c in plan if (c["a"], c["w"]) == ("bf16", "nv")} == {1, 4, 8, 16, 512} | mid | pre              # configs[1..2] + M = 512 + mid M + prefill
+    assert {c["M"] for c in plan if (c["a"], c["w"], c["mode"]) == ("bf16", "nv", "auto")} == {1, 4, 8, 16, 512} | mid | pre   # configs[1..2] + M = 512 + mid M + prefill
+    assert {(c["w"], c["mode"]) for c in plan if c["mode"].startswith("native")} == {(w_, "native_" + f_) for w_ in ("nv", "mx") for f_ in ("mxfp8", "mxfp6", "mxfp4")}
     assert {c["M"] for c in plan if c["mode"].startswith("native")} == {512} | pre
     # the largest cell stays inside what one 32-bit buffer descriptor / grid can address (csrc/api.hip gemm_impl refuses beyond: test_layout_and_abi)
     assert max(pre) * max(nk[0] for nk in BL.LLAMA70B.values()) * 2 < 1 << 32 and max(pre) * max(nk[1] for nk in BL.LLAMA70B.values()) < 1 << 32
@@ -1399,7 +1449,7 @@ def test_bench_cells_parity(pk):
                     sid, code = {"native_mxfp8": (pk.SOLUTION_AUTO_NATIVE_MXFP8, 2), "native_mxfp6": (pk.SOLUTION_AUTO_NATIVE_MXFP6, 4),
                                  "native_mxfp4": (pk.SOLUTION_AUTO_NATIVE_MXFP4, 6)}[mode]
                     picked = pk.ops.resolve_solution(P.hints(is_bf16), m, n, k, sid)
-                    assert picked and (picked >> 32) & 7 == code, tag
+                    assert picked and (picked >> 32) & 7 == code and (picked >> 28) & 0xF == (1 if w == "nv" else 2), tag
                     assert torch.count_nonzero(P.run(np.zeros_like(a), is_bf16, sid)) == 0, tag
                     check_native_sampled(P, sel(P.run(a, is_bf16, sid)), sel(a), code, f"{tag} -> {picked:#x}")
                 ran += 1
@@ -1955,6 +2005,166 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
     finally:
         pk.ops.set_workspace(None)
         pk.ops.enable_native_fp4(False)
+
+
+# --- NVFP4 weights on the native class (round 6): the MFMA-native image (csrc/nvnative.hip) and the WF = 6 kernels ----------------------
+
+def _nv_checkpoint_like(n, k, seed):
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import quantize_weights as QW
+    q, s, ws2 = QW.quantize_nvfp4(QW.synthetic_weights(n, k, seed=seed))
+    return q, s, float(ws2)
+
+
+@pytest.mark.parametrize("n,k,kind", [(32, 256, "uniform"), (48, 512, "uniform"), (272, 1024, "uniform"), (1024, 2048, "checkpoint"), (8192, 8192, "uniform")])
+def test_nv6_image_device_equals_host(pk, n, k, kind):
+    """petit_nvfp4_native_image (hardware convert v_cvt_scalef32_2xpk16_fp6_f32) and its host twin produce the same bytes -- negative scales, e4m3
+    subnormal scales, zero blocks, N % 32 == 16 (half-empty last block) included -- and the bytes decode to oracle.nv6_reencode."""
+    rng = np.random.default_rng(n * 3 + k)
+    if kind == "uniform":
+        q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+        s = rng.integers(0, 0x7F, (n, k // 16), dtype=np.uint8)
+        s[rng.random(s.shape) < 0.05] |= 0x80
+        q[rng.random((n, 1)).repeat(k // 2, axis=1) < 0.05] = 0          # whole zero rows (zero blocks)
+    else:
+        q, s, _ = _nv_checkpoint_like(n, k, n + k)
+    qd = torch.from_numpy(q).to(DEV)
+    b = pk.repack_nvfp4(qd.view(torch.int32), n, k)
+    sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+    image = pk.nvfp4_native_image(b, sp, n, k)
+    host = pk.offline.nvfp4_native_image_cpu(b.cpu(), sp.cpu(), n, k)
+    dev_bytes = image.cpu()
+    # (-0 elements: the sign of a zero product is the only bit the two may disagree on without changing a value; compare decoded values AND bytes)
+    if not torch.equal(dev_bytes, host):
+        d = pk.offline.nvfp4_native_image_dequant_cpu(dev_bytes, n, k).numpy()
+        h = pk.offline.nvfp4_native_image_dequant_cpu(host, n, k).numpy()
+        assert np.array_equal(d, h), "device and host images decode differently"
+        diff = (dev_bytes != host).sum().item()
+        raise AssertionError(f"{diff} image bytes differ although every decoded value agrees (sign of zero?)")
+    if n * k <= 1 << 22:
+        want, _ = O.nv6_reencode(q, s)
+        assert np.array_equal(pk.offline.nvfp4_native_image_dequant_cpu(dev_bytes, n, k).numpy(), want)
+
+
+@pytest.mark.parametrize("is_bf16", [True, False])
+@pytest.mark.parametrize("m,n,k", [(64, 256, 1024), (130, 96, 2048), (512, 1024, 2048), (33, 64, 512), (5, 64, 1024), (1, 128, 768), (257, 176, 1280), (200, 512, 4096)])
+def test_native_nvfp4_every_kernel(pk, m, n, k, is_bf16):
+    """Every enumerated native kernel of the NVFP4 family (the three activation formats, K split 1 / 2), on ragged M, N % 32 == 16 and every span size:
+    (1) exact semantics -- against the oracle run on the CPU-quantised activations and the image's weights (oracle.nv6_reencode) within the usual
+    1e-2 bound / the bound derived from the instruction; (2) the class tolerance against the unquantised oracle on the TRUE NVFP4 weights: the
+    activation class's bound plus the stated weight re-rounding bound."""
+    a_bits, q, s, gs = random_problem("nv", m, n, k, 7171 + m + n + k, is_bf16)
+    dtype = torch.bfloat16 if is_bf16 else torch.float16
+    h = pk.PetitSolutionHints()
+    h.a_type = h.c_type = dtype
+    h.b_type = pk.DataType.float4_e2m1
+    pk.ops.enable_native_fp4(False)
+    assert all((sid >> 48) & 0xF != 13 for sid in pk.ops.get_fp4_solutions(h, m, n, k))   # opt-in only
+    pk.ops.enable_native_fp4(True)
+    try:
+        native = [sid for sid in pk.ops.get_fp4_solutions(h, m, n, k) if (sid >> 48) & 0xF == 13]
+        assert {(sid >> 32) & 7 for sid in native} == {2, 4, 6}
+        qd = torch.from_numpy(q).to(DEV)
+        b = pk.repack_nvfp4(qd.view(torch.int32), n, k)
+        sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+        image = pk.nvfp4_native_image(b, sp, n, k)
+        gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+        ad = from_bits(a_bits, dtype).to(DEV)
+        a_f32 = to_f32(a_bits, is_bf16)
+        dq = O.dequant_nvfp4(q, s)
+        dq6, sb = O.nv6_reencode(q, s)
+        wb = np.maximum(2.0 ** -4 * np.abs(dq), np.repeat(np.ldexp(1.0, sb.astype(np.int64) - 127 - 4), 32, axis=1))
+        _, full = O.gemm_ref(a_bits, is_bf16, dq, gs)
+        sum_abs = (np.abs(a_f32) @ np.abs(dq).T) * gs
+        w_term = (np.abs(a_f32) @ wb.T) * gs
+        fin = np.isfinite(full) & (np.abs(full) < (3e38 if is_bf16 else 6e4))
+        for code, quant, fmt, coef in ((2, quantize_act_mxfp8, "mxfp8", 2e-2), (4, quantize_act_mxfp6, "mxfp6", 2e-2), (6, quantize_act_mxfp4, "mxfp4", 0.12)):
+            a_q = quant(a_f32)
+            _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq6, gs)
+            derived = native_exact_bound(a_q, dq6, gs, fmt)
+            for sid in [x for x in native if (x >> 32) & 7 == code]:
+                for splitk in (1, 2):
+                    sk = (sid & ~(0xF << 60)) | (splitk << 60)
+                    c = to_f32(bits(pk.mul_nvfp4_native(ad, image, gsd, m, n, k, sk)), is_bf16).astype(np.float64)
+                    err = np.abs(c - exact)[fin]
+                    assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all(), f"{sk:#x} max {err.max()}"
+                    assert np.median(err / np.maximum(np.abs(exact[fin]), 1e-3)) < (2 ** -8 if is_bf16 else 2 ** -11) * 1.5, f"{sk:#x}"
+                    assert (np.abs(c - full)[fin] <= (coef * sum_abs + w_term)[fin] + 1e-2).all(), f"{sk:#x}"
+            # pre-quantised activations (one launch) are bit-identical to quantising inside the call
+            sid0 = [x for x in native if (x >> 32) & 7 == code][0]
+            qa = pk.quantize_activations(ad, fmt)
+            assert torch.equal(pk.mul_nvfp4_native(qa, image, gsd, m, n, k, sid0).view(torch.int16), pk.mul_nvfp4_native(ad, image, gsd, m, n, k, sid0).view(torch.int16))
+        # the sentinels: through the class's own entry point, and -- once the image is attached -- through the reference's
+        a_q = quantize_act_mxfp8(a_f32)
+        _, exact = O.gemm_ref(O.f32_to_bf16_bits(a_q), True, dq6, gs)
+        derived = native_exact_bound(a_q, dq6, gs, "mxfp8")
+        bound = np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)
+        c1 = pk.mul_nvfp4_native(ad, image, gsd, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP8)
+        assert (np.abs(to_f32(bits(c1), is_bf16) - exact)[fin] <= bound[fin]).all()
+        exact_default = pk.mul_nvfp4_a16(ad, b, sp, gsd, m, n, k, -1)
+        assert torch.equal(pk.mul_nvfp4_a16(ad, b, sp, gsd, m, n, k, -2), exact_default)       # nothing attached: the library default, as in the reference
+        pk.attach_nvfp4_native(b, image)
+        try:
+            c2 = pk.mul_nvfp4_a16(ad, b, sp, gsd, m, n, k, -2)
+            assert torch.equal(c2.view(torch.int16), c1.view(torch.int16))
+            assert torch.equal(pk.mul_nvfp4_a16(ad, b, sp, gsd, m, n, k, -1), exact_default)   # -1 stays the exact class
+        finally:
+            pk.attach_nvfp4_native(b, None)
+        assert torch.equal(pk.mul_nvfp4_a16(ad, b, sp, gsd, m, n, k, -2), exact_default)
+        # fused SiLU-mul on the image (gate rows and up rows meet in one 32-row operand through the lanes' own addresses)
+        if n % 32 == 0 and fin.all() and np.abs(exact).max() < 50:
+            gate, up = exact.astype(np.float64)[:, : n // 2], exact.astype(np.float64)[:, n // 2:]
+            ref_act = gate / (1.0 + np.exp(-gate)) * up
+            for sid in [x for x in native if (x >> 32) & 7 == 2][:4]:
+                cf = to_f32(bits(pk.mul_nvfp4_native(ad, image, gsd, m, n, k, sid, activation="silu_mul")), is_bf16).astype(np.float64)
+                assert (np.abs(cf - ref_act) <= np.maximum(2e-2, 2e-2 * np.abs(ref_act))).all(), f"silu_mul {sid:#x}"
+    finally:
+        pk.ops.enable_native_fp4(False)
+
+
+def test_native_nvfp4_through_the_c_abi_and_a_graph(pk):
+    """petit_gemm_fp4_fp16_grid_ws with a native sentinel on NVFP4 weights: refused (PETIT_ERROR_KERNEL_SHAPE) without an image, runs on the attached
+    image with per-call scratch, is capturable into a HIP graph, and petit_gemm_nvfp4_native gives the same bits."""
+    from petit_kernel import _lib
+    import ctypes as C
+    m, n, k = 384, 512, 2048
+    a_bits, q, s, gs = random_problem("nv", m, n, k, 99, True)
+    b = pk.repack_nvfp4(torch.from_numpy(q).to(DEV).view(torch.int32), n, k)
+    sp = pk.process_nvfp4_scales(torch.from_numpy(s).to(DEV).view(torch.float8_e4m3fn), n, k)
+    image = pk.nvfp4_native_image(b, sp, n, k)
+    ad = from_bits(a_bits, torch.bfloat16).to(DEV)
+    gsd = torch.tensor([gs], dtype=torch.float32, device=DEV)
+    h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    sid = C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6)
+    need = int(_lib.lib.petit_gemm_workspace_bytes(C.byref(h), m, n, k, sid))
+    assert need >= m * k * 3 // 4
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    c = torch.zeros((m, n), dtype=torch.bfloat16, device=DEV)
+
+    def call(stream):
+        return _lib.lib.petit_gemm_fp4_fp16_grid_ws(c.data_ptr(), ad.data_ptr(), b.data_ptr(), sp.data_ptr(), gsd.data_ptr(), m, n, k, C.byref(h), sid, None,
+                                                    ws.data_ptr(), need, C.c_void_p(stream))
+    cur = torch.cuda.current_stream().cuda_stream
+    assert call(cur) == _lib.PETIT_ERROR_KERNEL_SHAPE and torch.count_nonzero(c) == 0
+    pk.attach_nvfp4_native(b, image)
+    try:
+        assert call(cur) == 0
+        want = pk.mul_nvfp4_native(ad, image, gsd, m, n, k, pk.SOLUTION_AUTO_NATIVE_MXFP6)
+        assert torch.equal(c.view(torch.int16), want.view(torch.int16))
+        assert _lib.lib.petit_gemm_fp4_fp16_grid_ws(c.data_ptr(), ad.data_ptr(), b.data_ptr(), sp.data_ptr(), gsd.data_ptr(), m, n, k, C.byref(h), sid, None,
+                                                    None, 0, C.c_void_p(cur)) == _lib.PETIT_ERROR_KERNEL_SHAPE     # no scratch: refused, not another class
+        c.zero_()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                assert call(st.cuda_stream) == 0
+            g.replay()
+            st.synchronize()
+        assert torch.equal(c.view(torch.int16), want.view(torch.int16))
+    finally:
+        pk.attach_nvfp4_native(b, None)
 
 
 def test_process_wide_default_class_runs_the_native_pick_behind_solution_id_minus_one(pk):

@@ -590,8 +590,8 @@ assert L.petit_tune_save(sys.argv[1].encode()) == 0
 
 
 def test_bench_line_stays_inside_the_drivers_record():
-    """The driver keeps the last ~16 KB of bench.py's stdout: the whole JSON line must fit with room to spare (<= 8 KB with every cell of the
-    plan present), the metric's own 16 cells (bf16 x NVFP4, M in {1, 8, 16, 512}, the four Llama-3-70B linears) must END the line, and the
+    """The driver keeps the last ~16 KB of bench.py's stdout: the whole JSON line must fit with room to spare (<= 12 KB with every cell of the
+    plan present: round 6 added the NVFP4 native cells and the TP = 8 shard shapes), the metric's own 16 cells (bf16 x NVFP4, M in {1, 8, 16, 512}, the four Llama-3-70B linears) must END the line, and the
     bf16 x MXFP4 decode cells (the reference's only MX activation type) must be in the plan.  No GPU: cells are synthesised from the plan."""
     import importlib.util
     import json
@@ -618,7 +618,7 @@ def test_bench_line_stays_inside_the_drivers_record():
             "host_us_per_call": {"x": "y" * 400}, "cells_method": "m" * 600, "cpu_baseline": {"value": 0.39, "unit": "GB/s", "cores": 128, "kind": "port", "sample": "s" * 200}}
     line.update(compact)
     text = json.dumps(line, separators=(",", ":"))
-    assert len(text) <= 8192, len(text)
+    assert len(text) <= 12288, len(text)
     assert sum(len(r[2]) for r in compact["cells"]) >= len(plan) and all(len(r[2]) == len(r[3]) == len(compact["cells_m"][r[1]]) for r in compact["cells"])
     assert list(line)[-1] == "metric_cells" and len(compact["metric_cells"]) == 16
     assert {(r[0], r[1]) for r in compact["metric_cells"]} == {(s, m) for s in BL.SHAPE_ORDER for m in (1, 8, 16, 512)}
@@ -627,7 +627,7 @@ def test_bench_line_stays_inside_the_drivers_record():
 
 def test_native_class_default_picks():
     """solution_id -2 / -3 (PETIT_SOLUTION_AUTO_NATIVE_MXFP8 / _MXFP4): the pick comes from the class's own table, else its own
-    model; it is always a native kernel of the requested activation format, exists for MXFP4 weights only, needs scratch, and
+    model; it is always a native kernel of the requested activation format, needs scratch, and
     PETIT_SOLUTION_AUTO itself never resolves to one."""
     from petit_kernel import _lib
     L = _lib.lib
@@ -656,9 +656,14 @@ def test_native_class_default_picks():
                 small = L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), None, C.c_uint64(_lib.lib.petit_native_workspace_bytes(m, k)))
                 assert small and (small >> 60) == 1 and (small ^ sid) & ~(0xF << 60) == 0
                 assert L.petit_gemm_resolve_solution(C.byref(h), m, n, k, C.c_uint64(sentinel), None, C.c_uint64(0)) == 0
+        # NVFP4 weights (round 6): the class exists there too -- on the MFMA-native image of the weights (test_nv6_entry_points_validate_without_a_gpu);
+        # its kernels carry the NVFP4 family's element nibble, and PETIT_SOLUTION_AUTO never resolves to one
         hn = _lib.SolutionHints(at, _lib.CXX_DTYPE_FP4_E2M1, at, 0)
-        assert L.petit_gemm_resolve_solution(C.byref(hn), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), None, C.c_uint64(1 << 40)) == 0
-        assert L.petit_gemm_workspace_bytes(C.byref(hn), 512, 8192, 8192, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)) == 0
+        for (m, n, k) in [(512, 8192, 8192), (300, 4096, 768), (64, 96, 512)]:
+            sid = L.petit_gemm_resolve_solution(C.byref(hn), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), None, C.c_uint64(1 << 40))
+            assert sid and (sid >> 48) & 0xF == 13 and (sid >> 28) & 0xF == 1 and (sid >> 32) & 7 == 6, hex(sid)
+            assert L.petit_gemm_workspace_bytes(C.byref(hn), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)) >= m * k // 2
+            assert (L.petit_gemm_default_solution(C.byref(hn), m, n, k) >> 48) & 0xF not in (9, 13)
 
 
 def test_process_wide_default_class_for_mxfp4_weights():
@@ -913,3 +918,67 @@ def test_native_silu_mul_without_slab_scratch_names_a_kernel_that_applies_it():
                     assert split > 1 or ntw % 2 == 0, (m, n, k, ws, hex(sid), _lib.describe_solution(sid))
                     if ws < 1 << 40:
                         assert split == 1 and ntw % 2 == 0, (hex(sid), _lib.describe_solution(sid))
+
+
+# --- the MFMA-native image of NVFP4 weights (csrc/nvnative.hip): the host twin against its numpy statement ------------------------
+
+def _checkpoint_like_nvfp4(n, k, seed):
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import quantize_weights as QW
+    q, s, ws2 = QW.quantize_nvfp4(QW.synthetic_weights(n, k, seed=seed))
+    return q, s, ws2
+
+
+@pytest.mark.parametrize("n,k,kind", [(32, 256, "uniform"), (48, 512, "uniform"), (64, 1024, "checkpoint"), (80, 768, "checkpoint"), (128, 2048, "checkpoint")])
+def test_nv6_image_host_twin_matches_its_statement(n, k, kind):
+    """petit_nvfp4_native_image_host + _dequant_host against oracle.nv6_reencode (E = floor(log2 max |fp4 x e4m3|) - 2, elements RNE to e2m3): every
+    value identical; the re-rounding stays inside the stated per-element bound (include/petit_amd.h) and moves checkpoint-like weights by ~2 % rms."""
+    import petit_kernel
+    rng = np.random.default_rng(n + k)
+    if kind == "uniform":
+        q = rng.integers(0, 256, (n, k // 2), dtype=np.uint8)
+        s = rng.integers(0, 0x7F, (n, k // 16), dtype=np.uint8)            # any non-NaN e4m3 byte, subnormals and zero included
+        s[rng.random(s.shape) < 0.05] |= 0x80                              # a few negative scales
+    else:
+        q, s, _ = _checkpoint_like_nvfp4(n, k, n + k)
+    b = petit_kernel.offline.repack_nvfp4_cpu(torch.from_numpy(q.copy()).view(torch.int32), n, k)
+    sp = petit_kernel.offline.process_nvfp4_scales_cpu(torch.from_numpy(s.copy()).view(torch.float8_e4m3fn), n, k)
+    image = petit_kernel.offline.nvfp4_native_image_cpu(b, sp, n, k)
+    assert image.numel() == ((n + 31) // 32) * (k // 128) * (3072 + 128)
+    got = petit_kernel.offline.nvfp4_native_image_dequant_cpu(image, n, k).numpy()
+    want, sbytes = O.nv6_reencode(q, s)
+    assert np.array_equal(got, want)
+    exact = O.dequant_nvfp4(q, s).astype(np.float64)
+    scale = np.repeat(np.ldexp(1.0, sbytes.astype(np.int64) - 127), 32, axis=1)
+    assert (np.abs(got - exact) <= np.maximum(2.0 ** -4 * np.abs(exact), scale * 2.0 ** -4)).all()
+    if kind == "checkpoint":
+        rel = np.sqrt(np.mean((got - exact) ** 2) / np.mean(exact ** 2))
+        assert rel < 0.03, rel
+
+
+def test_nv6_entry_points_validate_without_a_gpu():
+    from petit_kernel import _lib
+    L = _lib.lib
+    assert L.petit_nvfp4_native_image_bytes(8192, 8192) == 8192 * 8192 * 3 // 4 + 8192 * 8192 // 32
+    assert L.petit_nvfp4_native_image_bytes(200, 64) == 0 and L.petit_nvfp4_native_image_bytes(256, 24) == 0
+    assert L.petit_nvfp4_native_image_bytes(256, 48) == 2 * 2 * 3200          # N = 48: two n32-blocks, the second half empty
+    buf = (C.c_uint8 * 4096)()
+    assert L.petit_nvfp4_native_image_host(None, buf, buf, 256, 32) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    assert L.petit_nvfp4_native_image_host(buf, buf, buf, 200, 32) == _lib.PETIT_ERROR_PROBLEM_SHAPE
+    assert L.petit_nvfp4_native_attach(None, None) == _lib.PETIT_ERROR_BAD_ARGUMENT
+    assert L.petit_nvfp4_native_attach(C.addressof(buf), 256 * 7) == 0                      # (pointers are only remembered)
+    assert L.petit_nvfp4_native_attached(C.addressof(buf)) == 256 * 7
+    assert L.petit_nvfp4_native_attach(C.addressof(buf), 3) == _lib.PETIT_ERROR_BAD_ARGUMENT  # images are 256-byte aligned
+    assert L.petit_nvfp4_native_attach(C.addressof(buf), None) == 0
+    assert L.petit_nvfp4_native_attached(C.addressof(buf)) is None
+    # the native class on NVFP4 weights: sentinels resolve to kernels of the NVFP4 family (element_b nibble 1) with the scratch of the class
+    h = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1, _lib.CXX_DTYPE_BF16, 0)
+    for sentinel, code in ((_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, 2), (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, 4), (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 6)):
+        sid = L.petit_gemm_resolve_solution(C.byref(h), 1024, 8192, 8192, C.c_uint64(sentinel), None, C.c_uint64(1 << 40))
+        assert sid and (sid >> 48) & 0xF == 13 and (sid >> 28) & 0xF == 1 and (sid >> 32) & 7 == code, hex(sid)
+        assert L.petit_gemm_workspace_bytes(C.byref(h), 1024, 8192, 8192, C.c_uint64(sentinel)) >= 1024 * 8192 // 2
+    # ... and a call without an image is refused before anything is launched (no GPU needed to see it)
+    rc = L.petit_gemm_fp4_fp16_grid_ws(C.addressof(buf), C.addressof(buf), C.addressof(buf), C.addressof(buf), C.addressof(buf), 64, 64, 256, C.byref(h),
+                                       C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8), None, None, 0, None)
+    assert rc == _lib.PETIT_ERROR_KERNEL_SHAPE

@@ -65,6 +65,9 @@ def bench_cell_plan() -> list:
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="auto"), dict(shape=shape, M=512, a="fp16", w="mx", mode="auto"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp6"),
                  dict(shape=shape, M=512, a="bf16", w="mx", mode="native_mxfp4"),
+                 # (round 6) NVFP4 weights on the native class: the MFMA-native image of the same weights (petit_nvfp4_native_image, attached)
+                 dict(shape=shape, M=512, a="bf16", w="nv", mode="native_mxfp8"), dict(shape=shape, M=512, a="bf16", w="nv", mode="native_mxfp6"),
+                 dict(shape=shape, M=512, a="bf16", w="nv", mode="native_mxfp4"),
                  dict(shape=shape, M=512, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=512, a="fp8", w="dense", mode="hipblaslt_fp8")]
     # prefill (round 5): M > 512 up to the reference list's largest entries, exact NV / MX, the three native classes, the vendor's bf16 and FP8 GEMMs
     for shape in SHAPE_ORDER:
@@ -72,6 +75,8 @@ def bench_cell_plan() -> list:
             plan += [dict(shape=shape, M=m, a="bf16", w="nv", mode="auto"), dict(shape=shape, M=m, a="bf16", w="mx", mode="auto"),
                      dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp8"), dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp6"),
                      dict(shape=shape, M=m, a="bf16", w="mx", mode="native_mxfp4"),
+                     dict(shape=shape, M=m, a="bf16", w="nv", mode="native_mxfp8"), dict(shape=shape, M=m, a="bf16", w="nv", mode="native_mxfp6"),
+                     dict(shape=shape, M=m, a="bf16", w="nv", mode="native_mxfp4"),
                      dict(shape=shape, M=m, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=m, a="fp8", w="dense", mode="hipblaslt_fp8")]
         # (fp16 x MXFP4 at the largest chunk: the family x regime whose table rows named a 10 x slower kernel until round 5 re-measured them -- no cell had timed it)
         plan += [dict(shape=shape, M=PREFILL_MS[-1], a="fp16", w="mx", mode="auto")]
@@ -136,9 +141,36 @@ class Weights:
             else:
                 sp = torch.randint(119, 136, (n // 32, k), generator=gen, dtype=torch.uint8, device=dev)
             self.packed.append((b, sp))
+        self.images = []
 
     def __getitem__(self, i):
         return self.packed[i % self.copies]
+
+    def attach_native(self):
+        """NVFP4 weights on the native class: the MFMA-native image of every copy (petit_nvfp4_native_image: one launch each, load-time work, not
+        timed), attached to the copy's packed weight pointer -- what a serving stack does once after repack_nvfp4."""
+        if self.fmt != "nv" or self.images:
+            return
+        nbytes = int(_lib.lib.petit_nvfp4_native_image_bytes(self.k, self.n))
+        for b, sp in self.packed:
+            img = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+            rc = _lib.lib.petit_nvfp4_native_image(C.c_void_p(img.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(sp.data_ptr()), self.k, self.n,
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, rc
+            assert _lib.lib.petit_nvfp4_native_attach(C.c_void_p(b.data_ptr()), C.c_void_p(img.data_ptr())) == 0
+            self.images.append(img)
+        torch.cuda.synchronize()
+
+    def detach_native(self):
+        for (b, _), _img in zip(self.packed, self.images):
+            _lib.lib.petit_nvfp4_native_attach(C.c_void_p(b.data_ptr()), None)
+        self.images = []
+
+    def __del__(self):
+        try:
+            self.detach_native()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class Gemm:
@@ -180,6 +212,8 @@ class Gemm:
         return self._ws[need], need
 
     def launcher(self, sid: int):
+        if self.w.fmt == "nv" and sid in (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4):
+            self.w.attach_native()
         ws, need = self.workspace(sid)
         wsp = C.c_void_p(ws.data_ptr()) if ws is not None else None
         m, n, k = self.m, self.w.n, self.w.k
