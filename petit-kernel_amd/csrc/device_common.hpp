@@ -23,6 +23,9 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
+typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
+typedef __attribute__((ext_vector_type(16))) float f32x16v;
 
 enum : int { kFmtNv = 0, kFmtMx = 1 };
 
@@ -413,6 +416,35 @@ template <int KS> __device__ __forceinline__ unsigned mx_rec_outside_f16(const S
         acc |= (0x8C8C8C8Cu - x) | (x - 0x72727272u);
     }
     return acc & (KS >= 4 ? 0xE0E0E0E0u : 0x0000E0E0u); // (KS = 2: a two-byte record, zero-extended by its load)
+}
+
+// The 32-element FP6 converts, issued through inline asm with an EARLY-CLOBBER destination.  hipcc 7.2 treats the builtins
+// (__builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32, ..._pk32_fp6_{bf16,f16}) as ordinary VOP3 instructions and is free to place the scale operand (or part of
+// a source) inside the 6-register destination -- "v_cvt_scalef32_2xpk16_fp6_f32 v[34:39], v[2:17], v[18:33], v34" in the first build of nvnative.hip --
+// and the hardware writes the destination while it still reads its sources: elements 0-1 came out right, the other 30 saturated or flushed to zero
+// with the right sign (round 6; tools/probes/dbg_nv6.py).  "=&v" keeps the destination disjoint from every input.
+//   element 2 t = a[t], 2 t + 1 = b[t]; element i at bits [6 i, 6 i + 6); dst = RNE_e2m3(src / scale), saturating at 7.5 (tools/probes/mfma32_fp6_probe.hip)
+__device__ __forceinline__ u32x6 cvt_2xpk16_fp6_f32(const f32x16v a, const f32x16v b, const float scale) {
+    u32x6 out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_cvt_scalef32_2xpk16_fp6_f32 %0, %1, %2, %3" : "=&v"(out) : "v"(a), "v"(b), "v"(scale));
+#else
+    out = u32x6{0u, 0u, 0u, 0u, 0u, 0u};
+#endif
+    return out;
+}
+// 32 packed 16-bit values (16 dwords) -> 32 e2m3 codes; kBf16: the sources are bf16, else fp16
+template <bool kBf16> __device__ __forceinline__ u32x6 cvt_pk32_fp6_16bit(const u32x16 packed, const float scale) {
+    u32x6 out;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (kBf16)
+        asm("v_cvt_scalef32_pk32_fp6_bf16 %0, %1, %2" : "=&v"(out) : "v"(packed), "v"(scale));
+    else
+        asm("v_cvt_scalef32_pk32_fp6_f16 %0, %1, %2" : "=&v"(out) : "v"(packed), "v"(scale));
+#else
+    out = u32x6{0u, 0u, 0u, 0u, 0u, 0u};
+#endif
+    return out;
 }
 
 // Compile-time loop with a constant index (scale-record bytes, ring slots and

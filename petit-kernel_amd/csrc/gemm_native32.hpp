@@ -170,18 +170,9 @@ __global__ __launch_bounds__(256) void quantize_act32_fp6_kernel(const void *a, 
     unsigned sbyte = amax == 0.f ? 127u : (ebits > 2u ? ebits - 2u : 1u);
     sbyte = sbyte > 254u ? 254u : sbyte;
     const float scale = __builtin_bit_cast(float, sbyte << 23);
-    typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
-    typedef __attribute__((ext_vector_type(16))) unsigned u32x16;
     const u32x16 packed = u32x16{raw[0][0], raw[0][1], raw[0][2], raw[0][3], raw[1][0], raw[1][1], raw[1][2], raw[1][3],
                                  raw[2][0], raw[2][1], raw[2][2], raw[2][3], raw[3][0], raw[3][1], raw[3][2], raw[3][3]};
-    u32x6 q;
-    if constexpr (AT::kType == kDataTypeBf16) {
-        typedef __attribute__((ext_vector_type(32))) __bf16 bf16x32;
-        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_bf16(__builtin_bit_cast(bf16x32, packed), scale);
-    } else {
-        typedef __attribute__((ext_vector_type(32))) _Float16 f16x32;
-        q = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(__builtin_bit_cast(f16x32, packed), scale);
-    }
+    const u32x6 q = cvt_pk32_fp6_16bit<AT::kType == kDataTypeBf16>(packed, scale); // (early-clobber form: device_common.hpp)
     const unsigned kt = blk / 4, b = blk % 4;
     const size_t tile_row = (size_t)kt * m + row;
     *reinterpret_cast<u32x4 *>(qa_lo + tile_row * 64 + 16 * b) = u32x4{q[0], q[1], q[2], q[3]};
@@ -247,9 +238,8 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
             // the block's 32 columns are this lane's 16 and its partner's (lane ^ 32) 16: each converts a 32-wide vector that holds its own values at
             // their column positions and zeros (code 0) elsewhere; the two results OR into the block's 6 registers.  v_cvt_scalef32_2xpk16_fp6_f32
             // interleaves its sources (element 2 t = a[t], 2 t + 1 = b[t]: tools/probes/mfma32_fp6_probe.hip); column np 16 + u 8 + 4 h + i.
-            typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
             const float scale = __builtin_bit_cast(float, sbyte << 23);
-            f32x16 ea, eb;
+            f32x16v ea, eb;
 #pragma unroll
             for (int t = 0; t < 16; ++t)
                 ea[t] = 0.f, eb[t] = 0.f;
@@ -264,7 +254,7 @@ __device__ __forceinline__ void n32_silu_quant_epilogue(const f32x16 (&acc)[MB][
                         ea[t] = mine ? v[np][u][0] : ea[t], eb[t] = mine ? v[np][u][1] : eb[t];
                         ea[t + 1] = mine ? v[np][u][2] : ea[t + 1], eb[t + 1] = mine ? v[np][u][3] : eb[t + 1];
                     }
-            const u32x6 own = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ea, eb, scale);
+            const u32x6 own = cvt_2xpk16_fp6_f32(ea, eb, scale); // (early-clobber form: device_common.hpp)
             unsigned full[6];
 #pragma unroll
             for (int d = 0; d < 6; ++d) {

@@ -135,14 +135,12 @@ __global__ __launch_bounds__(256) void nv6_image_kernel(unsigned char *__restric
             float v[32];
             sbyte = block_values(w, ps[si], ps[si + 1], v);
 #if defined(__HIP_DEVICE_COMPILE__)
-            typedef __attribute__((ext_vector_type(6))) unsigned u32x6;
-            typedef __attribute__((ext_vector_type(16))) float f32x16;
-            f32x16 ea, eb; // element 2 t = ea[t], 2 t + 1 = eb[t] (tools/probes/mfma32_fp6_probe.hip)
+            f32x16v ea, eb; // element 2 t = ea[t], 2 t + 1 = eb[t] (tools/probes/mfma32_fp6_probe.hip)
 #pragma unroll
             for (int t = 0; t < 16; ++t)
                 ea[t] = v[2 * t], eb[t] = v[2 * t + 1];
             const float scale = bits_f32((sbyte == 0xffu ? 127u : sbyte) << 23);
-            const u32x6 qv = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(ea, eb, scale);
+            const u32x6 qv = cvt_2xpk16_fp6_f32(ea, eb, scale); // (early-clobber form: device_common.hpp)
 #pragma unroll
             for (int d = 0; d < 6; ++d)
                 words[d] = qv[d];

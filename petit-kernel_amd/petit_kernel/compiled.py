@@ -56,8 +56,10 @@ def _sid(solution_id: int) -> int:
     the K split in bits 60-63, so a split of 8..15 does not fit a signed int64 as such: it crosses as its two's-complement
     value and the binding reinterprets it.  Any negative id means "library default" (reference: fp4.cc:189-191)."""
     solution_id = int(solution_id)
-    if solution_id < 0:             # (the native class is reached through mul_mxfp4_native, never through the reference's entry points)
-        return -1
+    if solution_id < 0:
+        # -2 / -3 / -4 cross as they are: the binding reads them as the native-class sentinels ONLY for NVFP4 weights that have an MFMA-native image
+        # attached (attach_nvfp4_native: the caller's opt-in), as the library default everywhere else -- the reference's meaning of any negative id
+        return solution_id if solution_id >= -4 else -1
     if solution_id >= 1 << 64:
         raise RuntimeError(f"No kernel implementation for solution_id={solution_id}.")
     return solution_id - (1 << 64) if solution_id >= 1 << 63 else solution_id
