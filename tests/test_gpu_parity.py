@@ -1654,6 +1654,8 @@ def test_repeat_launch_bit_identical(pk, kind):
                 sp, mul = pk.process_mxfp4_scales(torch.from_numpy(s).to(DEV), n, k), pk.mul_mxfp4_a16
             ref = oracle_ref(kind, a_bits, True, q, s, gs)
             sum_abs = oracle_sum_abs(kind, a_bits, True, q, s, gs)
+            if kind == "nv":    # the native kernels of the NVFP4 family run on the weights' MFMA-native image (explicit ids find it attached to b)
+                pk.attach_nvfp4_native(b, pk.nvfp4_native_image(b, sp, n, k))
             cands = []
             for sid in pk.ops.get_fp4_solutions(h, m, n, k):
                 code, wm = (sid >> 48) & 0xF, (sid >> 36) & 0xF
@@ -1673,6 +1675,8 @@ def test_repeat_launch_bit_identical(pk, kind):
                     c = mul(a, b, sp, gsd, m, n, k, sid)
                     assert torch.equal(c.view(torch.int16), first.view(torch.int16)), f"{sid:#x} m={m} n={n} k={k}: launch {it} differs"
                     launches += 1
+            if kind == "nv":
+                pk.attach_nvfp4_native(b, None)
     finally:
         pk.ops.enable_native_fp4(False)
     assert launches >= 3000
@@ -2826,7 +2830,7 @@ def test_mlp_block_accuracy_budget_checkpoint_like_weights(pk):
             dq2i = pk.offline.nvfp4_native_image_dequant_cpu(img2.cpu(), hid, inter).numpy().astype(np.float64) * float(g2)
             ref_img = block(dq1i, dq2i)
             report["nvfp4_image"] = {"weight_rerounding_vs_exact_fp4": _rel_rms(ref_img, ref_fp4, rms), "total_vs_bf16_weight_block": _rel_rms(ref_img, ref_bf16, rms),
-                                     "weights_moved": float(np.mean(dq1i != dq1)), "weight_rms_change_over_weight_rms": float(np.sqrt(np.mean((dq1i - dq1) ** 2) / np.mean(dq1 ** 2)))}
+                                     "weights_moved": float(np.mean(np.abs(dq1i - dq1) > 1e-6 * np.abs(dq1))), "weight_rms_change_over_weight_rms": float(np.sqrt(np.mean((dq1i - dq1) ** 2) / np.mean(dq1 ** 2)))}
             for act, sid in (("mxfp8", pk.SOLUTION_AUTO_NATIVE_MXFP8), ("mxfp6", pk.SOLUTION_AUTO_NATIVE_MXFP6), ("mxfp4", pk.SOLUTION_AUTO_NATIVE_MXFP4)):
                 hq = pk.mul_nvfp4_native(pk.quantize_activations(xd, act), img1, g1, m, 2 * inter, hid, sid, activation="silu_mul", out_quantized=act)
                 yn = pk.mul_nvfp4_native(hq, img2, g2, m, hid, inter, sid).float().cpu().numpy().astype(np.float64)
@@ -2904,10 +2908,13 @@ def test_stacked_mlp_accuracy_budget_checkpoint_like_weights(pk, wfmt):
         (dump / ("stacked_mlp_accuracy_budget_checkpoint_like" + ("_nvfp4" if nv else "") + ".json")).write_text(json.dumps({"weights": wfmt, "layers": layers, "hidden": hid, "intermediate": inter, "m": m, "outlier_columns": 4,
                                                                                            "outlier_factor": 40, "mlp_gain": gain, "errors": report}, indent=1))
     assert report["exact"]["vs_exact_fp4_stack_over_update"] <= 2e-2
-    assert report["mxfp8"]["vs_exact_fp4_stack_over_update"] <= 0.15
-    assert report["mxfp6"]["vs_exact_fp4_stack_over_update"] <= 0.15
+    # (NVFP4: the image's weight re-rounding rides on top of the activation format -- measured 0.126 / 0.154 / 0.457 against 0.090 / 0.128 / 0.459 for MXFP4 weights)
+    assert report["mxfp8"]["vs_exact_fp4_stack_over_update"] <= (0.16 if nv else 0.15)
+    assert report["mxfp6"]["vs_exact_fp4_stack_over_update"] <= (0.19 if nv else 0.15)
     assert report["mxfp4"]["vs_exact_fp4_stack_over_update"] <= 0.8
     assert 0.02 <= report["weight_quantisation_oracle"] <= 0.6
+    # ... and stays a small part of what the 4-bit weight format itself costs: the total moves by < 10 % of it for the deployable classes
+    assert report["mxfp8"]["vs_bf16_weight_stack_over_update"] <= 1.10 * report["exact"]["vs_bf16_weight_stack_over_update"]
 
 
 def test_examples_run(pk):
