@@ -1371,17 +1371,20 @@ def test_native_class_table_rows_sampled(pk):
     exact semantics on the CPU-quantised activations, the class tolerance against the unquantised oracle -- and the resolved id IS the row's."""
     import re
     rows = re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}", (ROOT / "petit-kernel_amd/csrc/tuned_native_gfx950.inc").read_text())
-    rows = [(int(at), int(n), int(k), int(lo), int(hi), int(sol, 16)) for at, bt, n, k, lo, hi, sol in rows]
+    rows = [(int(at), int(n), int(k), int(lo), int(hi), int(sol, 16), int(bt)) for at, bt, n, k, lo, hi, sol in rows]
     assert len(rows) > 2000
     rng = np.random.default_rng(404)
     sentinels = {2: pk.SOLUTION_AUTO_NATIVE_MXFP8, 4: pk.SOLUTION_AUTO_NATIVE_MXFP6, 6: pk.SOLUTION_AUTO_NATIVE_MXFP4}
     ran = 0
     for code, sentinel in sentinels.items():
         pool = [r for r in rows if (r[5] >> 32) & 7 == code and r[0] == 5 and r[1] * r[2] <= 160e6 and (r[1], r[2]) not in LLAMA70B.values()]
-        for i in rng.choice(len(pool), 3, replace=False):
-            at, n, k, lo, hi, sol = pool[i]
+        # three rows of the MXFP4 family and (round 6) one of the NVFP4 family -- the kernels that run on the weights' MFMA-native image
+        picks = [pool[i] for i in rng.choice(len(pool), len(pool), replace=False)]
+        picks = [r for r in picks if r[6] == 7][:3] + [r for r in picks if r[6] == 3][:1]
+        assert len(picks) == 4
+        for at, n, k, lo, hi, sol, bt in picks:
             m = min(hi, 512)
-            P = FullSizeProblem(pk, "mx", n, k, 7000 + n + k)
+            P = FullSizeProblem(pk, "mx" if bt == 7 else "nv", n, k, 7000 + n + k)
             picked = pk.ops.resolve_solution(P.hints(True), m, n, k, sentinel)
             assert picked == sol, (n, k, m, hex(picked), hex(sol))
             a = P.activations(m, True, 7100 + m)
@@ -1389,7 +1392,7 @@ def test_native_class_table_rows_sampled(pk):
             ran += 1
             del P
             torch.cuda.empty_cache()
-    assert ran == 9
+    assert ran == 12
 
 
 def sampled_rows(m: int):

@@ -636,7 +636,8 @@ def test_native_class_default_picks():
     assert rows
     for at, bt, n, k, lo, hi, sol in rows:
         at, bt, n, k, lo, hi, sol = int(at), int(bt), int(n), int(k), int(lo), int(hi), int(sol, 16)
-        assert bt == _lib.CXX_DTYPE_MXFP4_E2M1 and (sol >> 48) & 0xF in (9, 13)
+        assert bt in (_lib.CXX_DTYPE_MXFP4_E2M1, _lib.CXX_DTYPE_FP4_E2M1) and (sol >> 48) & 0xF in (9, 13)
+        assert (sol >> 28) & 0xF == (2 if bt == _lib.CXX_DTYPE_MXFP4_E2M1 else 1)      # the family's element nibble: NVFP4 rows name the image kernels
         h = _lib.SolutionHints(at, bt, at, 0)
         sentinel = {6: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4, 4: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, 2: _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8}[(sol >> 32) & 7]
         assert L.petit_gemm_resolve_solution(C.byref(h), row_rep_m(lo, hi), n, k, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == sol
