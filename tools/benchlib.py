@@ -339,6 +339,10 @@ class HipblasLtGemm:
             lib.hbl_run.restype = C.c_int
             lib.hbl_run.argtypes = [C.c_void_p] * 5
             lib.hbl_destroy.argtypes = [C.c_void_p]
+            lib.hbl_count.restype = C.c_int
+            lib.hbl_count.argtypes = [C.c_void_p]
+            lib.hbl_select.restype = C.c_int
+            lib.hbl_select.argtypes = [C.c_void_p, C.c_int]
             HipblasLtGemm._lib = lib
         self.m, self.n, self.k = m, n, k
         fp8 = dtype == torch.float8_e4m3fn          # (the vendor's 8-bit GEMM: e4m3 operands, unit scales, bf16 output)
@@ -387,6 +391,41 @@ class HipblasLtGemm:
                 us.append(e0.elapsed_time(e1) * 1e3 / launches)
         med = median(us)
         return {"us": med, "us_min": min(us), "tflops": flops / med / 1e6, "launches": launches, "reps": reps, "launch": mode}
+
+    def time_best(self, stream, first: dict, max_algos: int = 24) -> dict:
+        """The fastest of the heuristic's results (the reference's `bench_matmul -algo tune`, matmul_hipblaslt.cc:220-247): every usable result gets a
+        short timing (3 x a few launches), the best one the full treatment of time().  `first` = time() of result 0.  Returns its dict + index / count."""
+        count = int(HipblasLtGemm._lib.hbl_count(self.h))
+        quick = {0: first["us"]}
+        flops = 2.0 * self.m * self.n * self.k
+        launches = int(max(3, min(30, 1000.0 / max(flops / (BF16_PEAK_TFLOPS * 1e6), 1.0))))
+        with torch.cuda.stream(stream):
+            for i in range(1, min(count, max_algos)):
+                if HipblasLtGemm._lib.hbl_select(self.h, i) != 0:
+                    continue
+                try:
+                    self.launch(0)
+                    stream.synchronize()
+                    us = []
+                    for _ in range(3):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(stream)
+                        for j in range(launches):
+                            self.launch(j)
+                        e1.record(stream)
+                        stream.synchronize()
+                        us.append(e0.elapsed_time(e1) * 1e3 / launches)
+                    quick[i] = median(us)
+                except RuntimeError:
+                    continue
+        best = min(quick, key=quick.get)
+        HipblasLtGemm._lib.hbl_select(self.h, best)
+        out = dict(first) if best == 0 else self.time(stream, reps=5)
+        if best != 0 and out["us"] > first["us"]:      # (the short timing flattered it)
+            out, best = dict(first), 0
+        HipblasLtGemm._lib.hbl_select(self.h, 0)
+        out.update({"algo_index": best, "algos_timed": len(quick), "algos_found": count})
+        return out
 
     def close(self):
         if self.h:

@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 constexpr size_t kWorkspace = 32u << 20; // matmul_hipblaslt.cc:25
@@ -18,6 +19,7 @@ struct Gemm {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t la = nullptr, lw = nullptr, lc = nullptr;
     hipblasLtMatmulAlgo_t algo;
+    std::vector<hipblasLtMatmulAlgo_t> algos; // every usable heuristic result, in the library's order (hbl_count / hbl_select)
     void *workspace = nullptr;
     size_t workspace_bytes = 0;
 };
@@ -51,15 +53,21 @@ void *hbl_create(int m, int n, int k, int is_bf16) {
     hipblasLtMatmulPreference_t pref = nullptr;
     HBL_TRY(hipblasLtMatmulPreferenceCreate(&pref));
     HBL_TRY(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &kWorkspace, sizeof(kWorkspace)));
-    hipblasLtMatmulHeuristicResult_t res[8];
+    // the reference's own tool asks for every algorithm the heuristic will name and times them all (`bench_matmul -algo tune`,
+    // tools/benchmarks/matmul/rocm/matmul_hipblaslt.cc:220-247: up to 10240 results); so does this comparator, up to kMaxAlgos: the FIRST
+    // usable result is what a plain hipBLASLt caller runs (reported as "hipblaslt"), the fastest of all of them as "hipblaslt_best"
+    constexpr int kMaxAlgos = 64;
+    std::vector<hipblasLtMatmulHeuristicResult_t> res(kMaxAlgos);
     int found = 0;
-    HBL_TRY(hipblasLtMatmulAlgoGetHeuristic(g->handle, g->desc, g->lw, g->la, g->lc, g->lc, pref, 8, res, &found));
+    HBL_TRY(hipblasLtMatmulAlgoGetHeuristic(g->handle, g->desc, g->lw, g->la, g->lc, g->lc, pref, kMaxAlgos, res.data(), &found));
     hipblasLtMatmulPreferenceDestroy(pref);
-    // the first candidate the library itself declares usable within the workspace
     int pick = -1;
-    for (int i = 0; i < found && pick < 0; ++i)
-        if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= kWorkspace)
-            pick = i;
+    for (int i = 0; i < found; ++i)
+        if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= kWorkspace) {
+            if (pick < 0)
+                pick = i;
+            g->algos.push_back(res[i].algo);
+        }
     if (pick < 0) {
         fprintf(stderr, "hipblaslt_gemm: no algorithm for m=%d n=%d k=%d (found %d)\n", m, n, k, found);
         return nullptr;
@@ -69,6 +77,16 @@ void *hbl_create(int m, int n, int k, int is_bf16) {
                 (size_t)res[pick].workspaceSize);
     g->algo = res[pick].algo;
     return g;
+}
+
+// usable heuristic results (>= 1 for a handle that exists); hbl_select(i) makes result i the one hbl_run launches (0 = the library's first choice)
+int hbl_count(void *handle) { return (int)static_cast<Gemm *>(handle)->algos.size(); }
+int hbl_select(void *handle, int i) {
+    Gemm *g = static_cast<Gemm *>(handle);
+    if (i < 0 || i >= (int)g->algos.size())
+        return -1;
+    g->algo = g->algos[i];
+    return 0;
 }
 
 // Enqueue one GEMM on `stream`.  0 on success.

@@ -73,6 +73,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nv-solution", default="", help="run ONLY bf16 x NVFP4 with this explicit kernel id (hex): for ablation libraries ($PETIT_AMD_LIB, tools/ablate_wide.sh)")
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "power_probe.json"))
+    ap.add_argument("--m", type=int, default=512, help="round 6: 16375 = the prefill chunk where the exact class trails the vendor (VERDICT r05 item 2a)")
+    ap.add_argument("--shapes", default="gate_up", help="comma-separated Llama-3-70B linears (tools/benchlib.py LLAMA70B)")
+    ap.add_argument("--seconds", type=float, default=2.5)
+    ap.add_argument("--no-native", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(dev)
@@ -97,70 +101,88 @@ def main():
         power, freq, cap = [power[mine]], [f for f in freq if f.parent == card_dir], [c for c in cap if c.parent == card_dir]
         del x
     out = {"sensors": {"power": [str(p) for p in power], "freq": [str(f) for f in freq],
-                       "power_cap_w": [int(c.read_text()) / 1e6 for c in cap] if cap else None}, "runs": []}
-    n, k, m = 57344, 8192, 512
-    flops = 2.0 * m * n * k
-    cases = []
-    if args.nv_solution:
-        w = BL.Weights("nv", n, k, 1280, dev)
-        g = BL.Gemm(w, m, torch.bfloat16, dev)
-        sid = int(args.nv_solution, 16)
-        from petit_kernel import _lib as _l
-        cases.append((f"bf16 x nvfp4 {_l.describe_solution(sid)[:60]}", g, sid))
-    for fmt, dt in (() if args.nv_solution else (("nv", torch.bfloat16), ("mx", torch.bfloat16))):
-        w = BL.Weights(fmt, n, k, 1280, dev)
-        g = BL.Gemm(w, m, dt, dev)
-        cases.append((f"bf16 x {fmt}fp4 default", g, None))
+                       "power_cap_w": [int(c.read_text()) / 1e6 for c in cap] if cap else None}, "m": args.m, "runs": []}
     from petit_kernel import _lib
-    extra = []
-    if not args.nv_solution:
-        wmx = BL.Weights("mx", n, k, 1280, dev)
-        for name, sent in (("native mxfp6", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6), ("native mxfp4", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), ("native mxfp8", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)):
-            g = BL.Gemm(wmx, m, torch.bfloat16, dev)
-            cases.append((name, g, sent))
-        extra = [("hipBLASLt bf16 dense", BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev, 1280), None)]
-    for name, g, sent in cases + extra:
-        if isinstance(g, BL.HipblasLtGemm):
-            launch = g.launch
+    for shape in args.shapes.split(","):
+        n, k = BL.LLAMA70B[shape]
+        m = args.m
+        flops = 2.0 * m * n * k
+        cases = []       # (name, factory) -- built one at a time: M = 16375 on gate_up is 1.9 GB of C per problem
+        if args.nv_solution:
+            sid = int(args.nv_solution, 16)
+            cases.append((f"bf16 x nvfp4 {_lib.describe_solution(sid)[:60]}", lambda: (BL.Gemm(BL.Weights("nv", n, k, 1280, dev), m, torch.bfloat16, dev), sid)))
         else:
-            launch = g.launcher(sent if sent is not None else _lib.PETIT_SOLUTION_AUTO)
-        launches = 64
-        with torch.cuda.stream(stream):
-            launch(0)
-            stream.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                for i in range(launches):
-                    launch(i)
-            for _ in range(3):
-                graph.replay()
-            stream.synchronize()
-            s = Sampler(power, freq)
-            s.start()
-            t0 = time.time()
-            reps = 0
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            while time.time() - t0 < 2.5:
-                graph.replay()
-                reps += 1
-                if reps % 4 == 0:
-                    stream.synchronize()
-            e1.record(stream)
-            stream.synchronize()
-            s.stop_flag = True
-            s.join()
-        ms = e0.elapsed_time(e1)
-        us = ms * 1e3 / (reps * launches)
-        tail = [x for x in s.samples if x[0] - t0 > 0.8]     # steady state
-        pws = sorted(x[1] for x in tail if x[1] is not None)
-        cks = sorted(x[2] for x in tail if isinstance(x[2], (int, float)))
-        rec = {"kernel": name, "us_per_launch": us, "tflops": flops / us / 1e6, "samples": len(tail),
-               "power_w_median": pws[len(pws) // 2] if pws else None, "power_w_max": pws[-1] if pws else None,
-               "sclk_mhz_median": cks[len(cks) // 2] if cks else None, "raw_clock_sample": tail[-1][2] if tail else None}
-        print(rec, flush=True)
-        out["runs"].append(rec)
-        time.sleep(1.0)
+            cases.append(("bf16 x nvfp4 default", lambda: (BL.Gemm(BL.Weights("nv", n, k, 1280, dev), m, torch.bfloat16, dev), None)))
+            cases.append(("bf16 x mxfp4 default", lambda: (BL.Gemm(BL.Weights("mx", n, k, 1280, dev), m, torch.bfloat16, dev), None)))
+            if not args.no_native:
+                for name, sent in (("native mxfp6", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6), ("native mxfp4", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4), ("native mxfp8", _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)):
+                    cases.append((name, lambda sent=sent: (BL.Gemm(BL.Weights("mx", n, k, 1280, dev), m, torch.bfloat16, dev), sent)))
+                cases.append(("nvfp4-image native mxfp8", lambda: (BL.Gemm(BL.Weights("nv", n, k, 1280, dev), m, torch.bfloat16, dev), _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8)))
+            cases.append(("hipBLASLt bf16 dense", lambda: (BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev, 1280), None)))
+            cases.append(("hipBLASLt bf16 dense, best of the heuristic's results", lambda: (BL.HipblasLtGemm(m, n, k, torch.bfloat16, dev, 1280), "best")))
+            cases.append(("hipBLASLt fp8 dense", lambda: (BL.HipblasLtGemm(m, n, k, torch.float8_e4m3fn, dev, 1280), None)))
+        for name, make in cases:
+            g, sent = make()
+            extra = {}
+            if isinstance(g, BL.HipblasLtGemm):
+                if sent == "best":
+                    rb = g.time_best(stream, g.time(stream, reps=3))
+                    BL.HipblasLtGemm._lib.hbl_select(g.h, rb["algo_index"])
+                    extra = {"algo_index": rb["algo_index"], "algos_timed": rb["algos_timed"], "algos_found": rb["algos_found"]}
+                launch, graphable = g.launch, False      # (hipBLASLt under stream capture faulted on one shape on this stack: eager, back to back)
+            else:
+                sid = sent if sent is not None else _lib.PETIT_SOLUTION_AUTO
+                launch, graphable = g.launcher(sid), True
+                extra = {"solution": f"{g.resolve(sid):x}"}
+            launches = max(4, min(64, int(64 * 512 / m)))
+            with torch.cuda.stream(stream):
+                launch(0)
+                stream.synchronize()
+                if graphable:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, stream=stream):
+                        for i in range(launches):
+                            launch(i)
+                    replay = graph.replay
+                else:
+                    def replay():
+                        for i in range(launches):
+                            launch(i)
+                for _ in range(3):
+                    replay()
+                stream.synchronize()
+                s = Sampler(power, freq)
+                s.start()
+                t0 = time.time()
+                reps = 0
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                while time.time() - t0 < args.seconds:
+                    replay()
+                    reps += 1
+                    if reps % 4 == 0:
+                        stream.synchronize()
+                e1.record(stream)
+                stream.synchronize()
+                s.stop_flag = True
+                s.join()
+            ms = e0.elapsed_time(e1)
+            us = ms * 1e3 / (reps * launches)
+            tail = [x for x in s.samples if x[0] - t0 > 0.8]     # steady state
+            pws = sorted(x[1] for x in tail if x[1] is not None)
+            cks = sorted(x[2] for x in tail if isinstance(x[2], (int, float)))
+            rec = {"shape": shape, "M": m, "kernel": name, "us_per_launch": us, "tflops": flops / us / 1e6, "samples": len(tail),
+                   "power_w_median": pws[len(pws) // 2] if pws else None, "power_w_max": pws[-1] if pws else None,
+                   "sclk_mhz_median": cks[len(cks) // 2] if cks else None, "raw_clock_sample": tail[-1][2] if tail else None,
+                   "joules_per_tflop": (pws[len(pws) // 2] * us * 1e-6) / (flops / 1e12) if pws else None}
+            rec.update(extra)
+            print(rec, flush=True)
+            out["runs"].append(rec)
+            if isinstance(g, BL.HipblasLtGemm):
+                g.close()
+            del g, launch
+            torch.cuda.empty_cache()
+            time.sleep(1.0)
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
     Path(args.out).write_text(json.dumps(out, indent=1))
 
