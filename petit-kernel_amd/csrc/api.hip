@@ -1559,9 +1559,10 @@ int petit_describe_solution(uint64_t id, char *buf, unsigned len) {
         return kOk;
     }
     if (s.am == kWideAm) {
-        snprintf(buf, len, "wide32 %sx%s ks%d mb%d np%d waves%d kgroups%d d%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x16 mfma)",
+        snprintf(buf, len, "wide32 %sx%s ks%d mb%d np%d waves%d kgroups%d d%d pf%d splitk%u  (wg tile %dx%d, %d threads, 32x32x16 mfma%s)",
                  a_type == kDataTypeBf16 ? "bf16" : "fp16", b_type == kDataTypeMxFp4e2m1 ? "mxfp4" : "nvfp4", s.ks,
-                 s.mt, s.nt / 2, s.wn, s.wm == 3 ? 2 : 1, s.d, s.pa, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * (s.wm == 3 ? 2 : 1));
+                 s.mt, s.nt / 2, s.wn, s.wm == 3 ? 2 : 1, s.d, s.pa, solution_splitk(id), 32 * s.mt, 16 * s.wn * s.nt, 64 * s.wn * (s.wm == 3 ? 2 : 1),
+                 s.wm == 6 ? ", fragments unpacked one group ahead, accumulators in AGPRs" : "");
         return kOk;
     }
     if (s.am == kTiledAm) {

@@ -6,5 +6,6 @@
 #define PETIT_TU_TABLE solutions_mx_f16
 #define PETIT_TU_NATIVE_AT Fp16
 #define PETIT_TU_QUANTIZE quantize32_f16
+#define PETIT_TU_NO_GA // (the group-ahead 32x32x16 form has no fast / fallback pair)
 #define PETIT_TU_PART 4
 #include "stream_tu.inc"

@@ -78,8 +78,16 @@ __device__ __forceinline__ void merge_tiles(unsigned x, unsigned y, unsigned &p1
 //   KG    wave GROUPS along K inside the workgroup (1 or 2), as Native32Cfg (gemm_native32.hpp): two complete copies of the wave set, each with its
 //         own LDS buffers and weight ring, half of the workgroup's K range each, accumulators summed through LDS before the epilogue -- two waves
 //         per SIMD for grids of ONE 128 x 128 tile per CU (`o`, qkv at M = 512), where gate_up gets them from two resident workgroups.
-template <class AT_, int FMT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int PF_ = 1, int KG_ = 1> struct WideCfg {
+//   GA    1 = "group ahead" (round 6, the 256 x 256 tile: MB = 8, NP = 2): the weight fragments are unpacked ONE GROUP ahead of their MFMAs instead
+//         of one step ahead -- 2 NP fragments (16 registers) in flight instead of the double-buffered step (128 registers at NP = 2) -- so that the
+//         256 architectural registers hold the activation fragments (64), the ring and the records while the 16 accumulator tiles (256 registers)
+//         live in AGPRs: one wave per SIMD, 16 MFMAs per group on 16 different accumulators, the W unpack amortised over 8 m-blocks and one
+//         activation-fragment read per two 32x32x16 MFMAs -- hipBLASLt's instruction mix at this M (MT256x256x64: 1.08 VALU and 0.25 LDS reads per
+//         16x16x32 MFMA, profiles/r06_prefill_pmc.json; the 128 x 256 tiled kernel: 2.9 (NVFP4) / 1.8 (MXFP4) VALU per MFMA).
+template <class AT_, int FMT_, int KS_, int MB_, int NP_, int WAVES_, int D_, int PF_ = 1, int KG_ = 1, int GA_ = 0> struct WideCfg {
     using AT = AT_;
+    static constexpr int GA = GA_;
+    static_assert(GA_ == 0 || (KG_ == 1 && PF_ == 1 && !AT_::kAdaptive), "group-ahead form: one K group, double-buffered A tile, plain 16-bit activations");
     static constexpr int FMT = FMT_, KS = KS_, MB = MB_, NP = NP_, WAVES = WAVES_, D = D_, PF = PF_, NBUF = PF_ + 1, KG = KG_;
     static constexpr int kThreads = 64 * WAVES * KG;
     static constexpr int BM = 32 * MB, BN = 32 * NP * WAVES;
@@ -295,6 +303,98 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
         for (int nt = 0; nt < 2 * NP; ++nt)
             wring[i][nt] = buf_load16(w_rsrc, w_voff[nt], (kt_begin + i) * kTileBytes, kAuxDefault);
 
+    if constexpr (Cfg::GA) {
+    // ---- group-ahead form (WideCfg GA = 1): see the note at WideCfg
+    Frag wfg[2][NP];
+    unsigned pw2[NP][4]; // P2's words, between the merge (chunk j) and their unpack (chunk 4 + j)
+    auto unpack_ga = [&](auto c_c, auto slot_c, auto t_c, const ScaleRec<FMT, KS> (*rc)[2]) {
+        constexpr int C = decltype(c_c)::value, SLOT = decltype(slot_c)::value, TS = decltype(t_c)::value, j = C % 4, q = C / 4;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            unsigned w;
+            if constexpr (q == 0) {
+                unsigned x = wring[SLOT][2 * np][j], y = wring[SLOT][2 * np + 1][j];
+                pin_here(x), pin_here(y);
+                merge_tiles(x, y, w, pw2[np][j]);
+            } else {
+                w = pw2[np][j];
+                pin_here(w);
+            }
+            float s_lo, s_hi;
+            tile_scales<FMT, KS, TS>(rc[np][q], s_lo, s_hi);
+            Frag f;
+            if constexpr (PETIT_ABLATE & 4)
+                f = __builtin_bit_cast(Frag, u32x4{w, w ^ __builtin_bit_cast(unsigned, s_lo), w, __builtin_bit_cast(unsigned, s_hi)});
+            else if constexpr (FMT == kFmtNv)
+                f = unpack_nv(AT{}, w, j < 2 ? s_lo : s_hi);
+            else
+                f = unpack_mx(AT{}, w, s_lo);
+            u32x4 fb = __builtin_bit_cast(u32x4, f);
+            pin_here(fb);
+            wfg[C & 1][np] = __builtin_bit_cast(Frag, fb);
+        }
+    };
+    unpack_ga(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, rec);
+    __syncthreads();
+    auto span_body = [&](const unsigned sp, auto last_c) {
+        constexpr bool kLast = decltype(last_c)::value;
+        const unsigned kt0 = sp * KS;
+        if constexpr (!kLast)
+            load_recs(rec_next, sp + 1);
+        static_for<0, KS>([&](auto t_c) {
+            constexpr int T = decltype(t_c)::value;
+            constexpr int SLOT = T % D, NSLOT = (T + 1) % D;
+            constexpr bool kNext = !kLast || (T + 1 < KS);
+            constexpr bool kRefill = !kLast || (T + D < KS);
+            constexpr int TN = (T + 1) % KS;
+            const unsigned kt = kt0 + T;
+            const u32x4 *const a_cur = smem + (T & 1) * Cfg::kBufU4;
+            u32x4 *const a_pf = smem + ((T + 1) & 1) * Cfg::kBufU4;
+            if constexpr (kNext && !(PETIT_ABLATE & 1))
+                dma_a_tile(a_pf, kt + 1); // everybody left that buffer at the barrier that ended the previous step
+            u32x4 fr[2][MB];
+            read_frags(a_cur, 0, fr[0]);
+            if constexpr (PETIT_ABLATE & 8)
+                read_frags(a_cur, 1, fr[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 8>([&](auto g_c) {
+                constexpr int g = decltype(g_c)::value;
+                if constexpr (g + 1 < 8 && !(PETIT_ABLATE & 8))
+                    read_frags(a_cur, g + 1, fr[(g + 1) & 1]);
+                // the group's MB * NP MFMAs on MB * NP different accumulators; chunk g + 1 (or chunk 0 of the next step) is unpacked in their shadow
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int np = 0; np < NP; ++np)
+                        acc[mb][np] = mfma32(wfg[g & 1][np], __builtin_bit_cast(Frag, fr[g & 1][mb]), acc[mb][np]);
+                if constexpr (g + 1 < 8) {
+                    unpack_ga(std::integral_constant<int, g + 1>{}, std::integral_constant<int, SLOT>{}, t_c, rec);
+                } else if constexpr (kNext) {
+                    if constexpr (TN == 0)
+                        unpack_ga(std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{}, std::integral_constant<int, 0>{}, rec_next);
+                    else
+                        unpack_ga(std::integral_constant<int, 0>{}, std::integral_constant<int, NSLOT>{}, std::integral_constant<int, TN>{}, rec);
+                }
+                if constexpr (g == 2 && kRefill && !(PETIT_ABLATE & 2)) { // chunk 3 has merged the slot's last word: tile t + D may land in it
+#pragma unroll
+                    for (int nt = 0; nt < 2 * NP; ++nt)
+                        wring[SLOT][nt] = buf_load16(w_rsrc, w_voff[nt], (kt + D) * kTileBytes, kAuxDefault);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if constexpr (kNext && !(PETIT_ABLATE & 32))
+                __syncthreads();
+        });
+        if constexpr (!kLast) {
+#pragma unroll
+            for (int np = 0; np < NP; ++np)
+                rec[np][0] = rec_next[np][0], rec[np][1] = rec_next[np][1];
+        }
+    };
+    for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
+        span_body(sp, std::false_type{});
+    span_body(sp_end - 1, std::true_type{});
+    } else {
     // Unpacked weight fragments, double buffered: the MFMAs of step t read wf[t % 2] while the words of step t + 1 are
     // merged and unpacked into wf[(t + 1) % 2] BETWEEN them, one chunk (one word of P1 or P2 per pair: 12 VALU for NVFP4)
     // per half-block, so the unpack hides in the shadow of the matrix pipe even with a single wave on the SIMD.
@@ -444,6 +544,7 @@ __global__ __launch_bounds__(Cfg::kThreads, Cfg::kMinWavesPerSimd) void gemm_wid
     for (unsigned sp = sp_begin; sp + 1 < sp_end; ++sp)
         span_body(sp, std::false_type{});
     span_body(sp_end - 1, std::true_type{});
+    } // (step-ahead form)
     } // (fast body)
     if constexpr (AT::kAdaptive) { // the join of the two bodies: see mfma_join_settle (device_common.hpp)
         static_for<0, 2>([&](auto pass) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ablate_wide.sh <bits> [<bits> ...] -- builds ablation variants of the large-M 32x32 kernel (PETIT_ABLATE bits, gemm_wide.hpp: 1 no A-tile DMA, 2 no W
-# refills, 4 no unpack VALU, 8 fragments read once, 16 no MFMA) as separate libraries under tools/ablate/wide/ (the bf16 x NVFP4 part-4 TU only -- tiled, wide32
+# refills, 4 no unpack VALU, 8 fragments read once, 16 no MFMA, 32 (group-ahead form) no step barrier) as separate libraries under tools/ablate/wide/ (the bf16 x NVFP4 part-4 TU only -- tiled, wide32
 # and shared kernels; every other object is the shipped one).  Run on the GPU box: PETIT_AMD_LIB=<lib> python tools/power_probe.py --nv-only (results are garbage,
 # only time / power count), or PETIT_AMD_LIB=<lib> python tools/tune.py --no-check --kinds 12 ...
 R=$(cd "$(dirname "$0")/.." && pwd)
