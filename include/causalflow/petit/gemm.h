@@ -68,6 +68,23 @@ struct SolutionId {
         __builtin_memcpy(&s, &r, 8);
         return s;
     }
+    // gemm.h:68-86 -- an id from the reference's field values (tile_k in elements / 16: the reference stores tile_k / 4 of a count in units of 4).  The
+    // three gfx950 fields start at their neutral values (one n-tile per wave is implied by tile_n / warp_partition_n, ring depth 0 = "as the kernel
+    // table says", no K split); an id built this way names a kernel of THIS build only if petit_gemm_get_solutions lists it.
+    static constexpr SolutionId MultiStage(MatmulFeatures features, MatmulElementB element_b, MatmulMfmaType mfma_type, unsigned tile_m, unsigned tile_n,
+                                           unsigned tile_k, MatmulWarpPartition warp_partition, unsigned warp_partition_m, unsigned warp_partition_n,
+                                           unsigned warp_partition_k) {
+        SolutionId s{};
+        s.tile_m = tile_m, s.tile_n = tile_n, s.tile_k = tile_k / 4, s.features = features, s.element_b = element_b, s.mfma_type = mfma_type;
+        s.warp_partition_m = warp_partition_m, s.warp_partition_n = warp_partition_n, s.warp_partition_k = warp_partition_k;
+        s.warp_partition = warp_partition, s.n_tiles_per_wave = 0, s.ring_depth = 0, s.split_k = 0;
+        return s;
+    }
+    // gemm.h:88-104 -- the reference's placeholder id (16 x 64 x 8, fp16 x NVFP4, warps 1 x 2 x 2); NOT the library default: that is
+    // (unsigned long)-1 = PETIT_SOLUTION_AUTO, as in the reference's callers (lib/pybind/fp4.cc:189-191)
+    static constexpr SolutionId Default() {
+        return MultiStage(kMatmulFeatures_Grid, kMatmulTypeBNvFp4, kMatmulMfmaTypeFp16, 1, 4, 8, kMatmulWarpPartition_NK, 1, 2, 2);
+    }
 };
 static_assert(sizeof(SolutionId) == 8, "SolutionId must stay a 64-bit value");
 

@@ -90,6 +90,12 @@ bool family_for(int a_type, int b_type, Family *out) {
 }
 
 bool shape_ok(unsigned n, unsigned k) { return n % kTileN == 0 && k % 256 == 0; }
+// ... and the ranges gemm_impl refuses with PETIT_ERROR_PROBLEM_SHAPE (32-bit buffer offsets inside one n-tile row / activation block; M beyond the tables'
+// last bucket): the enumeration and the default-pick queries answer "nothing" for exactly the problems the launcher would refuse (the reference's
+// enumeration filters by what its kernels accept, algo_chooser.cc:14-62) -- an empty problem (m, n or k = 0: the launcher's no-op) has no kernel either
+bool problem_in_range(unsigned m, unsigned n, unsigned k) {
+    return m != 0 && n != 0 && k != 0 && m <= kMaxM && (uint64_t)k * 16 * 4 * 2 < (1ull << 31) && (uint64_t)k * 64 * 4 < (1ull << 31);
+}
 
 // Can this entry run (m, n, k)?  KS has to match the layout K implies, and the
 // staged-activation kernels hold at most AM rows.
@@ -849,18 +855,20 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
         // M = 512 (0 of the 1104 measured rows there) -- so only the one that serves as the reference output is run
         if (!is_ref && m > 512 && s.am >= 0 && !is_batch(e))
             continue;
+        // the batched-decode kernels beyond their regime (16-128-row workgroups that each stream their whole column block: not beyond M = 1024 / eight
+        // m-blocks) are not candidates at all -- unsplit either (the cap used to sit below the push and only removed their K splits)
+        static const unsigned batch_max_m = [] { // $PETIT_AMD_BATCH_MAX_M: experiments with the batched-decode kernels beyond their regime
+            const char *v = getenv("PETIT_AMD_BATCH_MAX_M");
+            return v && *v ? (unsigned)strtoul(v, nullptr, 10) : 1024u; // (measured: the 128 x 128 form wins `o` / `down` at M = 512 by 3-10 %: profiles/r05_summary.md)
+        }();
+        if (!is_ref && is_batch(e) && (m > batch_max_m || m > 8u * 16u * (unsigned)s.mt))
+            continue;
         push(e, 1, is_ref);
         // K splits: the large-M kernels and the streaming kernels (direct and staged) take any split; the decode / shared-tile
         // kernels none
         // (measured: down 8192 x 28672 at M = 16, staged 16 x 64 tiles with a K split of 2: 29.0 us against 30.5 unsplit -- every CU
         // then pulls half of the activations)
         const bool splittable = s.am == kTiledAm || s.am == kWideAm || is_native_am(s.am) || (s.am >= 0 && s.am < kDecodeAm && s.wm == 1) || is_batch(e);
-        static const unsigned batch_max_m = [] { // $PETIT_AMD_BATCH_MAX_M: experiments with the batched-decode kernels beyond their regime
-            const char *v = getenv("PETIT_AMD_BATCH_MAX_M");
-            return v && *v ? (unsigned)strtoul(v, nullptr, 10) : 1024u; // (measured: the 128 x 128 form wins `o` / `down` at M = 512 by 3-10 %: profiles/r05_summary.md)
-        }();
-        if (is_batch(e) && (m > batch_max_m || m > 8u * 16u * (unsigned)s.mt))
-            continue; // (16-128-row workgroups that each stream their whole column block: not beyond M = 1024 / eight m-blocks)
         if (!splittable)
             continue;
         for (unsigned sk = 2; sk <= 8 && sk <= nspans; sk *= 2)
@@ -869,6 +877,9 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
     }
     return count;
 }
+
+// bulk + tail planning (gemm_impl): a dry run walks a call down to its launch -- kernel, split and scratch resolved, every refusal reported -- and stops there
+static thread_local bool tl_in_row_split = false, tl_dry_run = false;
 
 int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, const unsigned *scales,
               const float *global_scale, unsigned m, unsigned n, unsigned k,
@@ -959,19 +970,30 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
         entry = ch.entry, splitk = ch.splitk;
         if (!entry)
             return kErrKernelShape;
-        static thread_local bool in_row_split = false;
-        if (klass == kClassExact && !io && !in_row_split && !autotune_enabled()) {
+        // (io == nullptr: the entry points that take petit_native_args refuse PETIT_SOLUTION_AUTO, so petit_gemm_auto_row_split and
+        // petit_gemm_workspace_bytes_ex, which see hints only, describe exactly the calls that get here)
+        if (klass == kClassExact && !io && !tl_in_row_split && !autotune_enabled()) {
             if (const unsigned m1 = plan_row_split(*entry, splitk, m, n, k, arch_info(dev).num_cus)) {
-                // bulk + tail (plan_row_split): two default-pick calls on row ranges of A and C, same stream, same scratch (the launches are ordered)
-                in_row_split = true;
-                int rc = gemm_impl(b_type, c, a, b, scales, global_scale, m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
-                if (rc == kOk) {
-                    const size_t c_row = (act ? n / 2 : n) * sizeof(uint16_t), a_row = (size_t)k * sizeof(uint16_t);
-                    rc = gemm_impl(b_type, (unsigned *)((char *)c + m1 * c_row), (const unsigned *)((const char *)a + m1 * a_row), b, scales, global_scale,
-                                   m - m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
+                // bulk + tail (plan_row_split): two default-pick calls on row ranges of A and C, same stream, same scratch (the launches are ordered).
+                // BOTH are resolved (kernel, split, scratch) before either is launched: a tail that cannot run must not leave C half written or one launch
+                // in a stream capture -- the call then runs as the single launch it would have been.
+                const size_t c_row = (act ? n / 2 : n) * sizeof(uint16_t), a_row = (size_t)k * sizeof(uint16_t);
+                unsigned *const c2 = (unsigned *)((char *)c + m1 * c_row);
+                const unsigned *const a2 = (const unsigned *)((const char *)a + m1 * a_row);
+                tl_in_row_split = true;
+                tl_dry_run = true;
+                const bool both = gemm_impl(b_type, c, a, b, scales, global_scale, m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io) == kOk &&
+                                  gemm_impl(b_type, c2, a2, b, scales, global_scale, m - m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io) == kOk;
+                tl_dry_run = false;
+                int rc = kOk;
+                if (both) {
+                    rc = gemm_impl(b_type, c, a, b, scales, global_scale, m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
+                    if (rc == kOk)
+                        rc = gemm_impl(b_type, c2, a2, b, scales, global_scale, m - m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
                 }
-                in_row_split = false;
-                return rc;
+                tl_in_row_split = false;
+                if (both)
+                    return rc; // (a failure here is a launch error of the device: nothing a different plan would have avoided)
             }
         }
     } else {
@@ -1061,6 +1083,8 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
     // SiLU-mul: in the kernel's epilogue unsplit; by the reduce pass over plain slabs with a cross-workgroup K split
     args.act = (act && splitk == 1) ? 1u : 0u;
     args.reduce_act = (act && splitk > 1) ? 1u : 0u;
+    if (tl_dry_run)
+        return kOk;
     int rc = entry->launch(args, splitk, (hipStream_t)stream);
     if (rc == kErrSplitCollapsed) {
         // K is too short for the split the id (or the table row) names: the kernel runs as one part, so SiLU-mul is its own epilogue's job
@@ -1150,7 +1174,7 @@ uint64_t petit_gemm_workspace_bytes_ex(const petit_solution_hints *hints, unsign
         return 0;
     const petit_solution_hints eff = effective_hints(hints);
     hints = &eff;
-    if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
+    if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || !problem_in_range(m, n, k))
         return 0;
     if (is_auto_id(solution_id)) {
         int klass = auto_class(solution_id);
@@ -1336,7 +1360,7 @@ int petit_gemm_get_solutions(const petit_solution_hints *hints, unsigned m, unsi
     Family fam;
     unsigned count = 0;
     const unsigned cap = sols ? *n_sols : 0;
-    if (hints->c_type == hints->a_type && family_for(hints->a_type, hints->b_type, &fam) && shape_ok(n, k)) {
+    if (hints->c_type == hints->a_type && family_for(hints->a_type, hints->b_type, &fam) && shape_ok(n, k) && problem_in_range(m, n, k)) {
         for (int i = 0; i < fam.count; ++i) {
             if (!entry_fits(fam.entries[i], m, k))
                 continue;
@@ -1360,8 +1384,10 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
         return 0;
     const petit_solution_hints eff = effective_hints(hints);
     hints = &eff;
-    if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || m == 0)
+    if (hints->c_type != hints->a_type || !family_for(hints->a_type, hints->b_type, &fam) || !shape_ok(n, k) || !problem_in_range(m, n, k))
         return 0;
+    if (act && (n % 32 != 0 || (uint64_t)n * k / 2 >= (1ull << 32)))
+        return 0; // (gemm_impl: SiLU-mul needs gate / up halves of whole n-tiles inside one descriptor)
     if (!is_auto_id(solution_id)) {
         const SolutionEntry *e = find_explicit(fam, solution_id);
         const unsigned sk = solution_splitk(solution_id);
@@ -1370,6 +1396,8 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
         return make_solution_id(e->shape, fam.elem_b, entry_mfma(fam, *e), sk);
     }
     int klass = auto_class(solution_id);
+    if (klass != kClassExact && ((uint64_t)m * k >= (1ull << 32) || m > 65535u))
+        return 0; // (the native class's descriptor range: gemm_impl refuses the same)
     if (const int dflt = auto_default_class(solution_id, hints->b_type, m)) { // the process-wide default class, when `workspace_bytes` covers its pick (gemm_impl)
         const AutoChoice chn = choose_auto(fam, current_device(), hints->a_type, hints->b_type, act, m, n, k, dflt);
         if (chn.entry && workspace_need(*chn.entry, chn.splitk, m, n, k) <= workspace_bytes)

@@ -59,6 +59,7 @@ template <class AT_, int FMT_, int KS_, int MT_, int NT_, int WN_, int WK_, int 
     static_assert(MT >= 1 && MT <= 8 && (MT >= 2 || DA > 0), "1..8 m-tiles (MT = 1 without a loader wave is gemm_mid.hpp)");
     static_assert(DA > 0 || (kDma >= 1 && kDma * WN * 4 == BM), "the waves of a K part split a tile into whole KiB loads");
     static_assert(DA == 0 || (DA <= 4 && (DA > 1 ? (DA - 1) * kDma : 0) <= 63), "the loader's counted vmcnt is a 6-bit field");
+    static_assert(DA <= KS, "the loader's prologue requests DA tiles of the part's K range: a part is at least one span of KS tiles (ADVICE r05)");
     static_assert(KS % D == 0, "ring depth must divide the span");
     static_assert(!AT::kBfp, "plain bf16 / fp16 activations, or Fp16Mx (fast body + exact fallback, device_common.hpp) in the loader-wave form");
     static_assert(!AT::kAdaptive || (FMT == kFmtMx && DA > 0), "Fp16Mx: fp16 activations x MXFP4 weights, loader-wave form only");

@@ -107,6 +107,16 @@ std::vector<TunedEntry> read_rows(const char *path) {
         unsigned long long sol = 0;
         if (sscanf(line, "%d %d %u %u %u %u %llx", &e.a_type, &e.b_type, &e.n, &e.k, &e.m_lo, &e.m_hi, &sol) == 7 && e.m_lo >= 1 && e.m_hi >= e.m_lo) {
             e.solution = sol;
+            // A file saved by a build of rounds 1-4 has open-ended rows "257 .. 2^20" measured at M = 512; file rows are looked up before the built-in
+            // table, so such a row would hide the prefill buckets (513-1024, 1025-4096, 4097+) this build measures separately.  An open-ended row keeps
+            // the bucket its lower end lies in: 257 .. 2^20 -> 257 .. 512; a row that starts in the last bucket stays open-ended.
+            if (e.m_hi >= kMaxM) {
+                unsigned end = 1;
+                while (end < e.m_lo && end < 1024)
+                    end *= 2;
+                end = e.m_lo > 4096 ? kMaxM : e.m_lo > 1024 ? 4096u : end;
+                e.m_hi = end;
+            }
             rows.push_back(canonical_row(e));
         }
     }

@@ -396,11 +396,15 @@ void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const u
     rq.own_workspace = false, rq.ws = ws, rq.ws_bytes = ws ? ws_bytes : 0; // the candidates: what THIS caller's scratch can run
     rq.stream = stream, rq.persist = true;
     rq.rotate_bytes = (size_t)384 << 20; // past the 256 MB Infinity Cache (as far as the pool reaches)
-    // A key is tried ONCE per process, whatever the outcome: a failure (out of memory, a capture in progress on this stream, ...) must not be
-    // retried on every call, and neither must a success whose row some later lookup does not find (e.g. a row split by a later insert).
+    // A key is tuned ONCE per process: a success whose row some later lookup does not find (e.g. a row split by a later insert) is not repeated, and a
+    // transient failure (out of memory for the reference output / the rotation, a device error) gets kMaxAttempts tries PER KEY -- not a process-wide
+    // budget that one persistently failing key could use up for everybody.
+    constexpr int kMaxAttempts = 3;
     struct Key {
         int a_type, b_type;
         unsigned n, k, m_lo;
+        int attempts;   // tries so far
+        bool done;      // tuned, failed for good, or being tuned right now
     };
     static std::mutex seen_mutex;
     static std::vector<Key> seen;
@@ -413,27 +417,28 @@ void autotune_on_first_sight(int b_type, unsigned *c, const unsigned *a, const u
         (void)hipGetLastError();
         return;
     }
+    auto same = [&](const Key &f) { return f.a_type == a_type && f.b_type == rq.b_type && f.n == n && f.k == k && f.m_lo == lo; };
     {
         std::lock_guard<std::mutex> lock(seen_mutex);
-        for (const Key &f : seen)
-            if (f.a_type == a_type && f.b_type == rq.b_type && f.n == n && f.k == k && f.m_lo == lo)
-                return;
-        seen.push_back(Key{a_type, rq.b_type, n, k, lo});
+        bool found = false;
+        for (Key &f : seen)
+            if (same(f)) {
+                if (f.done)
+                    return;
+                f.done = true, ++f.attempts, found = true; // (a retry: this thread has it now)
+                break;
+            }
+        if (!found)
+            seen.push_back(Key{a_type, rq.b_type, n, k, lo, 1, true});
     }
     uint64_t best = 0;
     float us = 0.f;
     const int rc = tune_problem(rq, &best, &us);
     if (rc == kErrLaunch) {
-        // transient (out of memory for the reference output / the rotation, a device error): give the key a bounded number of further chances
-        static std::atomic<int> retries{8};
-        if (retries.fetch_sub(1) > 0) {
-            std::lock_guard<std::mutex> lock(seen_mutex);
-            for (size_t i = 0; i < seen.size(); ++i)
-                if (seen[i].a_type == a_type && seen[i].b_type == rq.b_type && seen[i].n == n && seen[i].k == k && seen[i].m_lo == lo) {
-                    seen.erase(seen.begin() + (long)i);
-                    break;
-                }
-        }
+        std::lock_guard<std::mutex> lock(seen_mutex);
+        for (Key &f : seen)
+            if (same(f) && f.attempts < kMaxAttempts)
+                f.done = false; // the next call of this problem tries again
     }
     if (rc != kOk)
         return;

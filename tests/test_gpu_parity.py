@@ -1281,6 +1281,14 @@ def native_exact_bound(a_q: np.ndarray, w: np.ndarray, gs: float, fmt: str) -> n
     return abs(gs) * out
 
 
+def native_p99_guard(err, exact, sum_abs, tag=""):
+    """native_exact_bound is a WORST case (every truncation a full unit, every block charged the final magnitude): on cancelling outputs it is
+    10-50 x looser than the empirical 4e-5 * sum|a||w| of rounds 3-4, which a kernel that dropped a low-order block contribution could hide under.  So next
+    to it: at most 1 % of the outputs may exceed max(one 16-bit rounding's 1e-2 bound, 4e-5 * sum|a||w|) -- the old tolerance as a p99, not as a maximum."""
+    over = err > np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), 4e-5 * sum_abs)
+    assert over.mean() <= 0.01, f"{tag}: {over.mean():.4f} of the outputs beyond the p99 guard"
+
+
 def check_native_sampled(P, c, a_bits, act_code, tag):
     """A native-FP4 kernel's output on FullSizeProblem P's sampled columns: (1) exact semantics against the oracle run on the
     CPU-quantised activations (usual 1e-2 bound), (2) the class's stated end-to-end tolerance against the unquantised oracle
@@ -1300,12 +1308,14 @@ def check_native_sampled(P, c, a_bits, act_code, tag):
         sum_abs = (np.abs(a_f32) @ np.abs(P.dq).T) * P.gs
         if P.kind == "nv":
             sum_abs = sum_abs + (np.abs(a_f32) @ P.w_rebound.T) * P.gs / {2: 2e-2, 4: 2e-2, 6: 0.12}[act_code]   # (enters as coef * sum_abs below)
-        cache[key] = (exact, full, sum_abs, native_exact_bound(a_q, dq_run, P.gs, {2: "mxfp8", 4: "mxfp6", 6: "mxfp4"}[act_code]))
-    exact, full, sum_abs, derived = cache[key]
+        cache[key] = (exact, full, sum_abs, native_exact_bound(a_q, dq_run, P.gs, {2: "mxfp8", 4: "mxfp6", 6: "mxfp4"}[act_code]),
+                      (np.abs(a_q) @ np.abs(dq_run).T) * P.gs)
+    exact, full, sum_abs, derived, sum_abs_q = cache[key]
     got = to_f32(bits(c[:, torch.from_numpy(P.rows).to(DEV)]), True).astype(np.float64)
     err = np.abs(got - exact)
     # (the derived per-output bound replaces rounds 3-4's empirical 1e-5 ... 4e-5 of sum|a||w|: native_exact_bound)
     assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)).all(), f"{tag}: exact-semantics max err {err.max()}"
+    native_p99_guard(err, exact, sum_abs_q, tag)
     # ... and much tighter on average (the derived bound is a worst case: every truncation a full unit, all in one direction): one 16-bit rounding
     assert np.median(err / np.maximum(np.abs(exact), 1e-3)) < 2 ** -8, f"{tag}: median relative error {np.median(err / np.maximum(np.abs(exact), 1e-3))}"
     coef = 2e-2 if act_code in (2, 4) else 0.12
@@ -1870,6 +1880,7 @@ def test_native_fp4_activations(pk, m, n, k, is_bf16):
                 c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sk), is_bf16).astype(np.float64)
                 err = np.abs(c - exact)[fin]
                 assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all(), f"{sk:#x} max {err.max()}"
+                native_p99_guard(err, exact[fin], ((np.abs(a_q) @ np.abs(dq).T) * gs)[fin], f"{sk:#x}")
                 assert (np.abs(c - full)[fin] <= 0.12 * sum_abs[fin] + 1e-2).all(), f"{sk:#x}"
                 assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 0.25 * np.sqrt(np.mean(full[fin] ** 2)), f"{sk:#x}"
     finally:
@@ -1928,6 +1939,7 @@ def test_native_mxfp6_activations(pk, m, n, k, is_bf16):
                 c = to_f32(run_case(pk, "mx", a_bits, is_bf16, q, s, gs, m, n, k, sk), is_bf16).astype(np.float64)
                 err = np.abs(c - exact)[fin]
                 assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all(), f"{sk:#x} max {err.max()}"
+                native_p99_guard(err, exact[fin], ((np.abs(a_q) @ np.abs(dq).T) * gs)[fin], f"{sk:#x}")
                 assert (np.abs(c - full)[fin] <= 2e-2 * sum_abs[fin] + 1e-2).all(), f"{sk:#x}"
                 assert np.sqrt(np.mean((c - full)[fin] ** 2)) <= 6e-2 * np.sqrt(np.mean(full[fin] ** 2)), f"{sk:#x}"
         # the class sentinel on its own entry point: an enumerated kernel of the class, same numbers
@@ -1991,6 +2003,7 @@ def test_native_mxfp4(pk, m, n, k, is_bf16):
             #     3-4 carried an empirical 1e-5 -> 2e-5 -> 4e-5 of sum|a||w| here, raised whenever a fuzz run found a worse element)
             err = np.abs(c - exact)[fin]
             assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all()
+            native_p99_guard(err, exact[fin], ((np.abs(a_q) @ np.abs(dq).T) * gs)[fin], f"{sid:#x}")
             assert np.median(err / np.maximum(np.abs(exact[fin]), 1e-3)) < (2 ** -8 if is_bf16 else 2 ** -11) * 1.5   # (typical: one 16-bit rounding)
             # (2) stated tolerance of the path against the UNQUANTISED reference: e4m3 activations carry
             #     up to 2^-4 relative error each; on these random problems the result stays within 2 %
@@ -2096,6 +2109,7 @@ def test_native_nvfp4_every_kernel(pk, m, n, k, is_bf16):
                     c = to_f32(bits(pk.mul_nvfp4_native(ad, image, gsd, m, n, k, sk)), is_bf16).astype(np.float64)
                     err = np.abs(c - exact)[fin]
                     assert (err <= np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), derived)[fin]).all(), f"{sk:#x} max {err.max()}"
+                    native_p99_guard(err, exact[fin], ((np.abs(a_q) @ np.abs(dq6).T) * gs)[fin], f"{sk:#x}")
                     assert np.median(err / np.maximum(np.abs(exact[fin]), 1e-3)) < (2 ** -8 if is_bf16 else 2 ** -11) * 1.5, f"{sk:#x}"
                     assert (np.abs(c - full)[fin] <= (coef * sum_abs + w_term)[fin] + 1e-2).all(), f"{sk:#x}"
             # pre-quantised activations (one launch) are bit-identical to quantising inside the call

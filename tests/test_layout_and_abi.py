@@ -85,6 +85,10 @@ def test_cxx_header_compiles_against_the_c_abi(tmp_path):
                    "  if (fp4::GemmGetSolutions(h, 1, 8192, 8192, nullptr, &n) != 0) return 1;\n"
                    "  if (n == 0 || n > 256) return 2; if (fp4::GemmGetSolutions(h, 1, 8192, 8192, ids, &n)) return 3;\n"
                    "  static_assert(sizeof(SolutionId) == 8, \"\");\n"
+                   # the reference's helpers (gemm.h:68-104), re-published: Default() = 16 x 64 x 8, fp16 x NVFP4, warps 1 x 2 x 2; MultiStage stores tile_k / 4
+                   "  if (SolutionId::Default().Repr() != (1ul | 4ul << 8 | 2ul << 16 | 1ul << 24 | 1ul << 28 | 1ul << 36 | 2ul << 40 | 2ul << 44)) return 5;\n"
+                   "  constexpr SolutionId ms = SolutionId::MultiStage(kMatmulFeatures_Grid, kMatmulTypeBMxFp4, kMatmulMfmaTypeBf16, 16, 16, 64, kMatmulWarpPartition_NK, 2, 2, 1);\n"
+                   "  if (ms.tile_k != 16 || ms.element_b != kMatmulTypeBMxFp4 || ms.warp_partition_m != 2 || ms.split_k != 0) return 6;\n"
                    "  return ids[0].element_b == kMatmulTypeBNvFp4 && ids[0].mfma_type == kMatmulMfmaTypeBf16 ? 0 : 4; }\n")
     from petit_kernel import _lib
     exe = tmp_path / "t"
@@ -327,6 +331,19 @@ def test_arch_table_rows_and_tune_file_override(tmp_path):
     tune.write_text(f"# a_type b_type n k m_lo m_hi solution\n{at} {bt} {n} {k} {lo} {lo} {other:x}\n")
     assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune)}, at, bt, lo, n, k) == other
     assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": ""}, at, bt, lo, n, k) == sol
+    # a file saved by a round 1-4 build: its open-ended "257 .. 2^20" row keeps the bucket it was measured in and no longer hides the prefill buckets
+    # this build measures separately
+    pre = next(r for r in rows if int(r[4]) == 4097)
+    at, bt, n, k, sol = int(pre[0]), int(pre[1]), int(pre[2]), int(pre[3]), int(pre[6], 16)
+    hints = _lib.SolutionHints(at, bt, at, 0)
+    cnt = C.c_uint(0)
+    _lib.lib.petit_gemm_get_solutions(C.byref(hints), 512, n, k, None, C.byref(cnt))
+    ids = (C.c_uint64 * cnt.value)()
+    _lib.lib.petit_gemm_get_solutions(C.byref(hints), 512, n, k, ids, C.byref(cnt))
+    old_pick = next(i for i in ids if (i >> 48) & 0xF == 8 and i != sol)
+    tune.write_text(f"{at} {bt} {n} {k} 257 {1 << 20} {old_pick:x}\n")
+    assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune)}, at, bt, 512, n, k) == old_pick
+    assert _default_solution_in_subprocess({"PETIT_AMD_TUNE_FILE": str(tune)}, at, bt, 8192, n, k) == sol
 
 
 def test_tune_file_native_row_is_ignored_for_auto(tmp_path):
@@ -900,6 +917,21 @@ def test_problem_ranges_are_refused_not_wrapped():
     for sentinel in (_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4):
         assert L.petit_gemm_mxfp4_native(p, p, p, p, p, 65535, 8192, 66560, C.byref(hm), C.c_uint64(sentinel), None, None, ws, C.c_uint64(1 << 40), None) == 1
         assert L.petit_gemm_mxfp4_native(p, p, p, p, p, 65536, 8192, 8192, C.byref(hm), C.c_uint64(sentinel), None, None, ws, C.c_uint64(1 << 40), None) == 1
+        # ... and the queries agree with the launcher (VERDICT r05 hygiene 8): no kernel, no scratch for a problem it refuses
+        assert L.petit_gemm_resolve_solution(C.byref(hm), 65536, 8192, 8192, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == 0
+        assert L.petit_gemm_resolve_solution(C.byref(hm), 65535, 8192, 66560, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) == 0
+        assert L.petit_gemm_resolve_solution(C.byref(hm), 512, 8192, 8192, C.c_uint64(sentinel), None, C.c_uint64(1 << 40)) != 0
+    # the enumeration and the default pick answer "nothing" exactly where the launcher refuses (M > 2^20) or has nothing to do (m, n or k = 0) --
+    # the reference's enumeration filters by what its kernels accept (algo_chooser.cc:14-62)
+    cnt = C.c_uint(0)
+    for hints in (h, hm):
+        for (m, n, k) in (((1 << 20) + 1, 8192, 8192), (1 << 21, 8192, 8192), (16, 0, 8192), (16, 8192, 0), (0, 8192, 8192)):
+            assert L.petit_gemm_default_solution(C.byref(hints), m, n, k) == 0, (m, n, k)
+            assert L.petit_gemm_get_solutions(C.byref(hints), m, n, k, None, C.byref(cnt)) == 0 and cnt.value == 0, (m, n, k)
+            assert L.petit_gemm_workspace_bytes(C.byref(hints), m, n, k, C.c_uint64(_lib.PETIT_SOLUTION_AUTO)) == 0
+            assert L.petit_gemm_auto_row_split(C.byref(hints), m, n, k, None) == 0
+        assert L.petit_gemm_default_solution(C.byref(hints), 1 << 20, 8192, 8192) != 0
+        assert L.petit_gemm_get_solutions(C.byref(hints), 1 << 20, 8192, 8192, None, C.byref(cnt)) == 0 and cnt.value > 0
 
 
 def test_native_silu_mul_without_slab_scratch_names_a_kernel_that_applies_it():
