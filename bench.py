@@ -131,8 +131,8 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
         dtype = torch.bfloat16 if a == "bf16" else torch.float16
         hbm = m <= BL.HBM_BOUND_MAX_M
         out = {"shape": shape, "M": m, "dt": f"{a}x{w}" + ("" if mode == "auto" else f" {mode}")}
-        if shape in BL.LLAMA70B:
-            n, k = BL.LLAMA70B[shape]
+        if shape in BL.ALL_SHAPES:
+            n, k = BL.ALL_SHAPES[shape]
         try:
             if shape == "tp8_qkv_3x1280":   # three TP-8 q / k / v shards sharing the activation row(s): three launches vs one grouped launch
                 key = ("grp", m)
@@ -143,6 +143,16 @@ def measure_cells(dev, stream, budget_s: float, sink=None, verbose: bool = False
                 if verbose:
                     print(f"[bench] cell {shape} M={m} {mode}", file=sys.stderr, flush=True)
                 r = weights[key].time(mode, stream)
+                out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "GBs": round(r["gbs"]), "frac": round(r["gbs"] / BL.HBM_PEAK_GBS, 4)})
+            elif shape == "tp8_layer":   # one decode layer's four GEMM launches at TP = 8 as a unit (BL.DecodeLayerTP8)
+                key = ("tp8_layer", m)
+                if key not in weights:
+                    weights.clear()
+                    torch.cuda.empty_cache()
+                    weights[key] = BL.DecodeLayerTP8(m, dev)
+                if verbose:
+                    print(f"[bench] cell tp8_layer M={m}", file=sys.stderr, flush=True)
+                r = weights[key].time(stream)
                 out.update({"us": round(r["us"], 2), "us_min": round(r["us_min"], 2), "GBs": round(r["gbs"]), "frac": round(r["gbs"] / BL.HBM_PEAK_GBS, 4)})
             elif shape == "mlp":      # gate_up -> SiLU-mul -> down of Llama-3-70B as one unit (BL.MlpBlock)
                 if "mlp" not in weights:

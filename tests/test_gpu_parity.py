@@ -1425,7 +1425,12 @@ def test_bench_cells_parity(pk):
     full_plan = BL.bench_cell_plan()
     assert [c["mode"] for c in full_plan if c["shape"] == "mlp"] == ["mlp_" + m_ for m_ in BL.MlpBlock.MODES]   # -> test_bench_mlp_block_cells
     assert {c["mode"] for c in full_plan if c["shape"].startswith("tp8")} == {"separate", "grouped"}            # -> test_grouped_launch
-    plan = [c for c in full_plan if not c["mode"].startswith("hipblaslt") and c["shape"] in BL.LLAMA70B]
+    assert [(c["M"], c["mode"]) for c in full_plan if c["shape"] == "tp8_layer"] == [(1, "layer"), (16, "layer")]                                # -> test_bench_tp8_layer_cells
+    every = [c for c in full_plan if not c["mode"].startswith("hipblaslt") and c["shape"] in BL.ALL_SHAPES]
+    # TP = 8 (round 6): the shard shapes of the reference's own list (tools/benchmarks/matmul.py:18-33) at decode and small-batch M, exact class
+    assert {(c["shape"], c["M"]) for c in every if c["shape"] in BL.TP8} == {(s_, m_) for s_ in BL.TP8_ORDER for m_ in (1, 16, 64, 512)}
+    assert all((c["a"], c["w"], c["mode"]) == ("bf16", "nv", "auto") for c in every if c["shape"] in BL.TP8)
+    plan = [c for c in every if c["shape"] in BL.LLAMA70B]
     assert {(c["a"], c["w"]) for c in plan} == {("bf16", "nv"), ("fp16", "nv"), ("fp16", "mx"), ("bf16", "mx")}
     mid, pre = set(BL.MID_MS), set(BL.PREFILL_MS)
     assert mid == {32, 44, 64, 128} and pre == {1024, 2084, 4314, 16375}   # the reference's representative M list, tools/benchmarks/matmul.py:8-90
@@ -1436,8 +1441,9 @@ def test_bench_cells_parity(pk):
     # the largest cell stays inside what one 32-bit buffer descriptor / grid can address (csrc/api.hip gemm_impl refuses beyond: test_layout_and_abi)
     assert max(pre) * max(nk[0] for nk in BL.LLAMA70B.values()) * 2 < 1 << 32 and max(pre) * max(nk[1] for nk in BL.LLAMA70B.values()) < 1 << 32
     ran = 0
-    for shape in BL.SHAPE_ORDER:
-        n, k = BL.LLAMA70B[shape]
+    plan = every
+    for shape in BL.SHAPE_ORDER + BL.TP8_ORDER:
+        n, k = BL.ALL_SHAPES[shape]
         for w in ("nv", "mx"):
             cells = [c for c in plan if c["shape"] == shape and c["w"] == w]
             if not cells:
@@ -1631,6 +1637,52 @@ def test_bench_mlp_block_cells(pk):
     for fmt, tol in (("mxfp4", 0.12), ("mxfp8", 0.03), ("mxfp6", 0.03)):
         rel = (outs[fmt + "_pipeline"] - outs[fmt + "_4launch"]).pow(2).mean().sqrt().item() / rms
         assert rel <= tol, (fmt, rel)
+
+
+@pytest.mark.parametrize("m", [1, 16])
+def test_bench_tp8_layer_cells(pk, m):
+    """bench.py's `tp8_layer` cells (tools/benchlib.py DecodeLayerTP8: the four GEMM launches of one Llama-3-70B layer on one GPU of a TP = 8 deployment, chained)
+    through the same calls: every stage against the oracle on the GPU's own input of that stage (sampled output columns; the grouped q / k / v launch is
+    compared bit for bit with separate calls in test_grouped_launch)."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import benchlib as BL
+    L = BL.DecodeLayerTP8(m, DEV, rotate_mb=64)
+    q, k_, v, o, h, y = L.run(1)
+    torch.cuda.synchronize()
+    gs = float(L.gs.item())
+    rng = np.random.default_rng(17 + m)
+
+    def unpacked(wts, i, n, kk):
+        # (the bench draws PACKED bytes: any bytes are a valid weight matrix -- read them back through the layout model)
+        from oracle import cdna4_layout as LY
+        b, sp = wts[i]
+        qw = LY.unpack_weights(b.cpu().numpy().view(np.uint32).ravel(), n, kk)
+        sc = LY.unpack_nvscales(sp.view(torch.uint8).cpu().numpy().ravel(), n, kk)
+        return qw.view(np.uint8).reshape(n, kk // 2), sc
+
+    def check(out, x, wts, n, kk, act=False, tag=""):
+        qb, sb = unpacked(wts, 1, n, kk)
+        n_out = n // 2 if act else n
+        cols = np.unique(np.concatenate([rng.integers(0, n_out, 40), [0, n_out - 1]]))
+        xb = bits(x)
+        if act:
+            dq = O.dequant_nvfp4(np.concatenate([qb[cols], qb[cols + n_out]]), np.concatenate([sb[cols], sb[cols + n_out]])).astype(np.float64)
+            y1 = to_f32(xb, True).astype(np.float64) @ dq.T * gs
+            g, u = y1[:, : len(cols)], y1[:, len(cols):]
+            want = g / (1.0 + np.exp(-g)) * u
+            got = out[:, torch.from_numpy(cols).to(DEV)].float().cpu().numpy().astype(np.float64)
+            assert (np.abs(got - want) <= 2e-2 * np.abs(want) + 2e-2 * np.sqrt(np.mean(want ** 2)) + 1e-6).all(), tag
+        else:
+            _, want = O.gemm_ref(xb, True, O.dequant_nvfp4(qb[cols], sb[cols]), gs)
+            check_gemm(bits(out[:, torch.from_numpy(cols).to(DEV)]), want, True)
+
+    check(q, L.x, L.wq, 1024, 8192, tag="q")
+    check(k_, L.x, L.wk, 128, 8192, tag="k")
+    check(v, L.x, L.wv, 128, 8192, tag="v")
+    check(o, q, L.wo, 8192, 1024, tag="o")
+    check(h, o, L.wgu, 7168, 8192, act=True, tag="gate_up + SiLU-mul")
+    check(y, h, L.wd, 8192, 3584, tag="down")
 
 
 # the kernels whose step-ending wait is a counted `s_waitcnt vmcnt(N)` + raw `s_barrier` (a wrong count is a timing-dependent

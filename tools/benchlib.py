@@ -40,6 +40,12 @@ LLAMA70B = {"qkv": (10240, 8192), "o": (8192, 8192), "gate_up": (57344, 8192), "
 #   "hipblaslt" = the vendor's dense 16-bit GEMM on a dense weight of the same shape (comparator, no parity to check);
 #   "hipblaslt_fp8" = the vendor's FP8 (e4m3 x e4m3 -> bf16) GEMM on the same shape: what the native class competes with
 SHAPE_ORDER = ("qkv", "o", "gate_up", "down")
+# The deployment the reference's README describes -- Llama-3.3-70B on 8 GPUs, TP = 8 -- in the shard shapes of its own benchmark list
+# (tools/benchmarks/matmul.py:18-33): what ONE GPU runs per layer (round 6).  `o` has K = 1024: one span of 8 k-tiles.
+TP8 = {"tp8_qkv": (1280, 8192), "tp8_o": (8192, 1024), "tp8_gate_up": (7168, 8192), "tp8_down": (8192, 3584)}
+TP8_ORDER = tuple(TP8)
+TP8_MS = (1, 16, 64, 512)
+ALL_SHAPES = {**LLAMA70B, **TP8}
 
 
 MID_MS = (32, 44, 64, 128)                  # batched decode: between the decode kernels and the large-M tiles (tools/benchmarks/matmul.py:8-90 lists 15, 44, ...)
@@ -80,6 +86,10 @@ def bench_cell_plan() -> list:
                      dict(shape=shape, M=m, a="bf16", w="dense", mode="hipblaslt"), dict(shape=shape, M=m, a="fp8", w="dense", mode="hipblaslt_fp8")]
         # (fp16 x MXFP4 at the largest chunk: the family x regime whose table rows named a 10 x slower kernel until round 5 re-measured them -- no cell had timed it)
         plan += [dict(shape=shape, M=PREFILL_MS[-1], a="fp16", w="mx", mode="auto")]
+    # TP = 8 (round 6): the four shard shapes at decode and small-batch M, and ONE decode layer's four launches as a unit (DecodeLayerTP8)
+    for shape in TP8_ORDER:
+        plan += [dict(shape=shape, M=m, a="bf16", w="nv", mode="auto") for m in TP8_MS]
+    plan += [dict(shape="tp8_layer", M=m, a="bf16", w="nv", mode="layer") for m in (1, 16)]
     # launch-gap-bound shapes: the q / k / v shards of a TP-8 deployment (1280 x 8192 each) as three launches and as one grouped launch
     plan += [dict(shape="tp8_qkv_3x1280", M=m, a="bf16", w="nv", mode=mode) for m in (1, 16) for mode in ("separate", "grouped")]
     # the gated-MLP block (gate_up -> SiLU-mul -> down) as a unit: what the quantising epilogue buys the native class
@@ -131,7 +141,7 @@ class Weights:
         self.fmt, self.n, self.k = fmt, n, k
         self.group = 16 if fmt == "nv" else 32
         wbytes = n * k // 2 + n * k // self.group
-        self.copies = int(max(2, min(max_copies, (rotate_mb << 20) // wbytes + 2)))
+        self.copies = int(max(2, min(max_copies, (rotate_mb << 20) // wbytes + 2))) if rotate_mb else int(max_copies)   # (rotate_mb = 0: exactly max_copies)
         gen = torch.Generator(device=dev).manual_seed(seed)
         self.packed = []
         for _ in range(self.copies):
@@ -270,6 +280,49 @@ class GroupedGemm:
         us = time_graph(lambda i: self.launch(mode, i), launches, reps, stream)
         med = median(us)
         return {"us": med, "us_min": min(us), "gbs": self.bytes / med / 1e3}
+
+
+class DecodeLayerTP8:
+    """The four GEMM launches of ONE Llama-3-70B layer on one GPU of a TP = 8 deployment, at M tokens, bf16 x NVFP4, chained the way the layer chains
+    them (attention itself is not this library's): q / k / v shards (1024 / 128 / 128 x 8192) as ONE grouped launch -> `o` (8192 x 1024, on the q output:
+    a stand-in for the attention output of the same shape) -> gate_up (7168 x 8192) with fused SiLU-mul -> down (8192 x 3584).  Every replay reads
+    a different copy of all four weight sets (nothing is served by the Infinity Cache).  Reported: microseconds per layer and the fraction of
+    (sum of the algorithmic bytes of the four GEMMs) / 8 TB/s."""
+
+    def __init__(self, m: int, dev, rotate_mb: int = 1280):
+        self.m, self.dev = m, dev
+        per_layer = sum(n * k * 9 // 16 for n, k in ((1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)))
+        copies = int(max(2, min(32, (rotate_mb << 20) // per_layer + 2)))
+        self.wq = Weights("nv", 1024, 8192, 0, dev, seed=21, max_copies=copies)
+        self.wk = Weights("nv", 128, 8192, 0, dev, seed=22, max_copies=copies)
+        self.wv = Weights("nv", 128, 8192, 0, dev, seed=23, max_copies=copies)
+        self.wo = Weights("nv", 8192, 1024, 0, dev, seed=24, max_copies=copies)
+        self.wgu = Weights("nv", 7168, 8192, 0, dev, seed=25, max_copies=copies)
+        self.wd = Weights("nv", 8192, 3584, 0, dev, seed=26, max_copies=copies)
+        for w in (self.wq, self.wk, self.wv, self.wo, self.wgu, self.wd):
+            w.copies = copies
+        gen = torch.Generator(device=dev).manual_seed(5)
+        self.x = torch.randn((m, 8192), generator=gen, device=dev, dtype=torch.float32).bfloat16()
+        self.gs = torch.tensor([0.02], dtype=torch.float32, device=dev)
+        self.bytes = sum(alg_bytes(m, n, k, 16) for n, k in ((1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)))
+        self.flops = 2.0 * m * sum(n * k for n, k in ((1280, 8192), (8192, 1024), (7168, 8192), (8192, 3584)))
+
+    def run(self, i: int = 0):
+        import petit_kernel as pk
+        m, gs = self.m, self.gs
+        members = [(self.wq[i][0], self.wq[i][1], gs, 1024), (self.wk[i][0], self.wk[i][1], gs, 128), (self.wv[i][0], self.wv[i][1], gs, 128)]
+        if m <= 16:
+            q, k_, v = pk.mul_fp4_a16_grouped("nvfp4", self.x, members, m, 8192, -1)
+        else:
+            q, k_, v = (pk.mul_nvfp4_a16(self.x, b, sp, g, m, n, 8192, -1) for b, sp, g, n in members)
+        o = pk.mul_nvfp4_a16(q, self.wo[i][0], self.wo[i][1], gs, m, 8192, 1024, -1)
+        h = pk.mul_nvfp4_a16(o, self.wgu[i][0], self.wgu[i][1], gs, m, 7168, 8192, -1, activation="silu_mul")
+        return q, k_, v, o, h, pk.mul_nvfp4_a16(h, self.wd[i][0], self.wd[i][1], gs, m, 8192, 3584, -1)
+
+    def time(self, stream, reps: int = 7, launches: int = 40) -> dict:
+        us = time_graph(lambda i: self.run(i), launches, reps, stream)
+        med = median(us)
+        return {"us": med, "us_min": min(us), "gbs": self.bytes / med / 1e3, "tflops": self.flops / med / 1e6, "launches": launches, "reps": reps}
 
 
 class MlpBlock:
