@@ -176,11 +176,17 @@ bool env_on(const char *name) {
 } // namespace
 
 void tune_bucket(unsigned m, uint64_t solution, unsigned *m_lo, unsigned *m_hi) {
-    // the M buckets of the built-in table (tools/make_tuned_inc.py): 1, 2, 3-4, 5-8, 9-16, 17-32, 33-64, 65-128, 129-256, 257-512, 513-1024,
+    // the M buckets of the built-in table (tools/make_tuned_inc.py): 1, 2, 3-4, 5-8, 9-16, 17-32, 33-48, 49-64, 65-128, 129-256, 257-512, 513-1024,
     // 1025-4096, 4097+ (round 5: the prefill buckets above 512 are their own rows -- a pick measured at M = 512 says little about M = 16375)
     unsigned lo = 1, hi = 1;
     while (hi < m && hi < 1024)
         lo = hi + 1, hi *= 2;
+    if (lo == 33) { // (round 6) 33-48 / 49-64: 48-row tiles (MT = 3 batched-decode instances) serve the lower half
+        if (m <= 48)
+            hi = 48;
+        else
+            lo = 49;
+    }
     if (m > 4096)
         lo = 4097, hi = kMaxM;
     else if (m > 1024)

@@ -288,6 +288,7 @@ def _default_solution_in_subprocess(env_extra, a_type, b_type, m, n, k):
 # upper end is not a measurement.  At THAT M solution_id = -1 resolves to exactly the row; elsewhere in the bucket to the same kernel, possibly with
 # a smaller K split (csrc/api.hip guarded_splitk).
 def row_rep_m(lo, hi):
+    # ((49, 64): what is left of a 33-64 row after a 48-row kernel took 33-48: still measured at 64)
     return 8192 if hi == 1 << 20 else 2048 if (lo, hi) == (1025, 4096) else hi
 
 
