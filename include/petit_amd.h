@@ -178,6 +178,12 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
  * the problem as a whole; resolve them at (rows) and (m - rows) for the two launches.  No reference counterpart: the reference's
  * 234-kernel chooser (fp4/algo_chooser.cc:64-132) takes the grid as it comes. */
 unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue);
+/* The same for any solution_id (round 6).  PETIT_SOLUTION_AUTO: as above.  A native-class sentinel: the rows the call runs IN THE CLASS when its grid of 128-row tiles
+ * ends a little past a whole number of rounds -- the remaining few dozen rows (<= 256) then go through the EXACT default pick (a batched-decode kernel: the class has no
+ * small-M kernel), i.e. they are computed exactly, never less accurately than the class promises; both parts share the call's scratch.  Only for calls that hand over 16-bit
+ * activations and take a 16-bit result (no petit_native_args formats) and, for NVFP4 weights, through the entry point that has the packed tensors (the attached image).
+ * 0 = one launch (always for explicit ids). */
+unsigned petit_gemm_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id, const petit_epilogue *epilogue);
 /* A test aid: the C tile (n-tile column *bn, m-tile row *bm) that workgroup `block` (= blockIdx.y * gridDim.x + blockIdx.x) of an nx x ny grid of the
  * large-M kernels computes under the XCD-aware raster with bands of `band` m-tiles (0 = whole columns) -- the very function the kernels call
  * (csrc/device_common.hpp tile_of_linear), so that its bijection is checked without a GPU.  No reference counterpart (the reference's grid is

@@ -338,6 +338,24 @@ void petit_raster_tile(unsigned nx, unsigned ny, unsigned band, unsigned block, 
         *bm = m_;
 }
 
+unsigned petit_gemm_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, uint64_t solution_id, const petit_epilogue *epilogue) {
+    if (solution_id == PETIT_SOLUTION_AUTO)
+        return petit_gemm_auto_row_split(hints, m, n, k, epilogue);
+    Family fam;
+    bool ok;
+    const bool act = epilogue_act(epilogue, &ok);
+    const int klass = auto_class(solution_id);
+    if (!ok || !hints || klass == kClassExact)
+        return 0; // (explicit ids run as named)
+    const petit_solution_hints eff = effective_hints(hints);
+    if (eff.c_type != eff.a_type || !family_for(eff.a_type, eff.b_type, &fam) || !shape_ok(n, k) || !problem_in_range(m, n, k) || autotune_enabled() ||
+        (uint64_t)m * k >= (1ull << 32) || m > 65535u)
+        return 0;
+    const int dev = current_device();
+    const AutoChoice ch = choose_auto(fam, dev, eff.a_type, eff.b_type, act, m, n, k, klass);
+    return ch.entry ? plan_row_split_native(*ch.entry, klass, ch.splitk, m, n, k, arch_info(dev).num_cus) : 0;
+}
+
 unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue) {
     Family fam;
     bool ok;

@@ -75,6 +75,7 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
 int auto_class(uint64_t solution_id);
 bool is_auto_id(uint64_t solution_id);
 unsigned plan_row_split(const SolutionEntry &e, unsigned splitk, unsigned m, unsigned n, unsigned k, int num_cus);
+unsigned plan_row_split_native(const SolutionEntry &e, int klass, unsigned splitk, unsigned m, unsigned n, unsigned k, int num_cus);
 extern std::atomic<int> g_mxfp4_default_class; // -1: $PETIT_AMD_MXFP4_ACTIVATIONS not read yet
 int mxfp4_default_class();
 int auto_default_class(uint64_t solution_id, int b_type, unsigned m);

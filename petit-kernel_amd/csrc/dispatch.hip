@@ -263,6 +263,28 @@ int gemm_impl(int b_type, unsigned *c, const unsigned *a, const unsigned *b, con
                     return rc; // (a failure here is a launch error of the device: nothing a different plan would have avoided)
             }
         }
+        // the native class at a ragged prefill M (plan_row_split_native, pick.hip): bulk in the class, the few dozen rows of the tail through the exact default
+        if (klass != kClassExact && restrict_ == 0 && !(io && io->image) && !tl_in_row_split && !autotune_enabled()) {
+            if (const unsigned m1 = plan_row_split_native(*entry, klass, splitk, m, n, k, arch_info(dev).num_cus)) {
+                const size_t c_row = (act ? n / 2 : n) * sizeof(uint16_t), a_row = (size_t)k * sizeof(uint16_t);
+                unsigned *const c2 = (unsigned *)((char *)c + m1 * c_row);
+                const unsigned *const a2 = (const unsigned *)((const char *)a + m1 * a_row);
+                tl_in_row_split = true;
+                tl_dry_run = true;
+                const bool both = gemm_impl(b_type, c, a, b, scales, global_scale, m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io) == kOk &&
+                                  gemm_impl(b_type, c2, a2, b, scales, global_scale, m - m1, n, k, hints, PETIT_SOLUTION_AUTO, epilogue, call_ws, call_ws_bytes, stream, nullptr) == kOk;
+                tl_dry_run = false;
+                int rc = kOk;
+                if (both) {
+                    rc = gemm_impl(b_type, c, a, b, scales, global_scale, m1, n, k, hints, solution_id, epilogue, call_ws, call_ws_bytes, stream, io);
+                    if (rc == kOk)
+                        rc = gemm_impl(b_type, c2, a2, b, scales, global_scale, m - m1, n, k, hints, PETIT_SOLUTION_AUTO, epilogue, call_ws, call_ws_bytes, stream, nullptr);
+                }
+                tl_in_row_split = false;
+                if (both)
+                    return rc;
+            }
+        }
     } else {
         entry = find_explicit(fam, solution_id);
         if (!entry)

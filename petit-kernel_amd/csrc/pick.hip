@@ -307,6 +307,44 @@ unsigned plan_row_split(const SolutionEntry &e, unsigned splitk, unsigned m, uns
     return best < 0.95 * whole ? best_rows : 0;
 }
 
+// The same plan for the NATIVE class (round 6): a sentinel call whose grid of 128-row tiles ends a little past a whole number of rounds
+// (`o` at M = 2084: 544 workgroups on 512 slots) runs its first m1 rows -- whole m-tiles, whole rounds -- in the class, and the remaining few dozen rows through
+// the EXACT default pick (a batched-decode kernel: one more pass over W; the class has no small-M kernel, a 36-row tail would pay a 128-row tile at a fraction
+// of the chip).  The tail rows are computed exactly -- never less accurately than the class promises; the quantised-activation scratch is k-tile major, so each
+// part quantises its own rows (stream order lets them share the scratch).  Not with pre-quantised input / quantised output (one layout for all rows), and not
+// when the image came per call without the packed tensors (petit_gemm_nvfp4_native).
+unsigned plan_row_split_native(const SolutionEntry &e, int klass, unsigned splitk, unsigned m, unsigned n, unsigned k, int num_cus) {
+    const StreamShape &s = e.shape;
+    if (row_split_disabled() || m <= 512 || splitk != 1 || s.am != kNative32Am)
+        return 0;
+    unsigned bm, bn;
+    entry_tile(e, &bm, &bn);
+    const bool two = s.wm == 1 && s.mt * s.nt == 16 && s.d == 2; // Native32Cfg: the 128 x 256 two-tile-ring forms fit two workgroups per CU
+    const double slots = num_cus * (two ? 2.0 : 1.0);
+    const unsigned nx = (n + bn - 1) / bn, ny = (m + bm - 1) / bm;
+    const double r = (double)nx * ny / slots;
+    if (r <= 1.0 || ny < 2)
+        return 0;
+    auto rounds = [](double x) { return x <= 1.0 ? 1.0 : 0.5 * (x + std::ceil(x - 1e-9)); };
+    const double tflops = klass == kClassNativeFp8 ? 2300.0 : klass == kClassNativeFp6 ? 2800.0 : 3300.0; // what the class sustains on a full chip (bench cells)
+    const double t_round = 2.0 * bm * bn * (double)k * slots / (tflops * 1e6);
+    const double whole = rounds(r) * t_round;
+    const double w_us = (double)n * k * 0.5625 / 4.5e6;
+    double best = whole;
+    unsigned best_rows = 0;
+    const unsigned span = (unsigned)(slots / nx) + 2;
+    for (unsigned cut = 1; cut < ny && cut <= span; ++cut) {
+        const unsigned ny1 = ny - cut, m1 = ny1 * bm, m2 = m - m1;
+        if (m2 > 256)
+            break; // (a longer tail is a compute-bound problem of its own: it stays in the class)
+        const double tail = 8.0 + std::max(w_us, 2.0 * m2 * (double)n * k / 0.8e9);
+        const double cost = rounds((double)nx * ny1 / slots) * t_round + tail;
+        if (cost < best)
+            best = cost, best_rows = m1;
+    }
+    return best < 0.95 * whole ? best_rows : 0;
+}
+
 // A process-wide opt-in for call sites that cannot name a sentinel (an unchanged SGLang / vLLM layer calls mul_mxfp4_a16(..., -1)):
 // $PETIT_AMD_MXFP4_ACTIVATIONS = mxfp8 | mxfp6 | mxfp4, or petit_set_mxfp4_default_class(), makes PETIT_SOLUTION_AUTO on MXFP4 weights
 // mean "the default pick of THAT native class" for m >= $PETIT_AMD_NATIVE_MIN_M (default 64: below it the exact kernels are HBM-bound and

@@ -83,6 +83,7 @@ _SIGNATURES = {
                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint)]),
     "petit_gemm_default_solution": (C.c_uint64, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint]),
     "petit_gemm_auto_row_split": (C.c_uint, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_void_p]),
+    "petit_gemm_row_split": (C.c_uint, [C.POINTER(SolutionHints), C.c_uint, C.c_uint, C.c_uint, C.c_uint64, C.POINTER(Epilogue)]),
     "petit_raster_tile": (None, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "petit_repack_nvfp4_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),
     "petit_repack_nvfp4_scales": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p]),

@@ -331,12 +331,13 @@ def resolve_solution(hints: PetitSolutionHints, size_m: int, size_n: int, size_k
                                                     C.byref(epi) if act else None, C.c_uint64(workspace_bytes)))
 
 
-def auto_row_split(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, activation=None) -> int:
-    """Rows of the first of the TWO launches a default-pick call at this (ragged prefill) M runs as, 0 = one launch (petit_gemm_auto_row_split)."""
+def auto_row_split(hints: PetitSolutionHints, size_m: int, size_n: int, size_k: int, activation=None, solution_id: int = -1) -> int:
+    """Rows of the first of the TWO launches a default-pick call at this (ragged prefill) M runs as, 0 = one launch (petit_gemm_row_split).  solution_id -2 / -4 / -3:
+    the rows a native-class call runs in the class -- the short tail goes through the exact default pick."""
     ch = _c_hints(hints)
     act = _ACTIVATIONS[activation]
     epi = _lib.Epilogue(None, act, 0)
-    return int(_lib.lib.petit_gemm_auto_row_split(C.byref(ch), size_m, size_n, size_k, C.cast(C.pointer(epi), C.c_void_p) if act else None))
+    return int(_lib.lib.petit_gemm_row_split(C.byref(ch), size_m, size_n, size_k, C.c_uint64(_c_solution_id(solution_id, native_ok=True)), C.byref(epi) if act else None))
 
 
 def dequant_packed(B: torch.Tensor, s: torch.Tensor, size_n: int, size_k: int, kind: str = "nvfp4", dtype=torch.float32,
