@@ -179,7 +179,7 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
  * 234-kernel chooser (fp4/algo_chooser.cc:64-132) takes the grid as it comes. */
 unsigned petit_gemm_auto_row_split(const petit_solution_hints *hints, unsigned m, unsigned n, unsigned k, const petit_epilogue *epilogue);
 /* The same for any solution_id (round 6).  PETIT_SOLUTION_AUTO: as above.  A native-class sentinel: the rows the call runs IN THE CLASS when its grid of 128-row tiles
- * ends a little past a whole number of rounds -- the remaining few dozen rows (<= 256) then go through the EXACT default pick (a batched-decode kernel: the class has no
+ * ends a little past a whole number of rounds -- the remaining few dozen rows (<= 128) then go through the EXACT default pick (a batched-decode kernel: the class has no
  * small-M kernel), i.e. they are computed exactly, never less accurately than the class promises; both parts share the call's scratch.  Only for calls that hand over 16-bit
  * activations and take a 16-bit result (no petit_native_args formats) and, for NVFP4 weights, through the entry point that has the packed tensors (the attached image).
  * 0 = one launch (always for explicit ids). */

@@ -335,8 +335,9 @@ unsigned plan_row_split_native(const SolutionEntry &e, int klass, unsigned split
     const unsigned span = (unsigned)(slots / nx) + 2;
     for (unsigned cut = 1; cut < ny && cut <= span; ++cut) {
         const unsigned ny1 = ny - cut, m1 = ny1 * bm, m2 = m - m1;
-        if (m2 > 256)
-            break; // (a longer tail is a compute-bound problem of its own: it stays in the class)
+        if (m2 > 128)
+            break; // (a longer tail is a compute-bound problem of its own: it stays in the class.  Measured, profiles/r06_native_row_split_ab.jsonl: tails of 36 rows
+                   // at M = 2084 gain 6-25 % on `o` / `down`, both weight formats, all three activation formats; tails of 218 rows at M = 4314 -3 ... +1 %)
         const double tail = 8.0 + std::max(w_us, 2.0 * m2 * (double)n * k / 0.8e9);
         const double cost = rounds((double)nx * ny1 / slots) * t_round + tail;
         if (cost < best)

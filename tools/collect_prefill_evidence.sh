@@ -21,12 +21,17 @@ for SH in o gate_up; do
   run ${SH}_mx        python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt mx --iters 6
   run ${SH}_hbl_first python3 $R/tools/profile_hipblaslt.py --m $M --n $N --k $K --iters 6
   run ${SH}_hbl_best  python3 $R/tools/profile_hipblaslt.py --m $M --n $N --k $K --iters 6 --algo best
+  # the native class at the same M (why the MFMA pipe is 0.6 busy): MXFP4 weights raw and NVFP4 weights on their image, MXFP8 activations; the vendor's FP8 GEMM
+  PETIT_AMD_NO_ROW_SPLIT=1 run ${SH}_native_mx_mxfp8 python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt mx --sentinel mxfp8 --iters 6
+  PETIT_AMD_NO_ROW_SPLIT=1 run ${SH}_native_nv_mxfp8 python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt nv --sentinel mxfp8 --iters 6
+  PETIT_AMD_NO_ROW_SPLIT=1 run ${SH}_native_mx_mxfp4 python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt mx --sentinel mxfp4 --iters 6
+  run ${SH}_hbl_fp8   python3 $R/tools/profile_hipblaslt.py --m $M --n $N --k $K --iters 6 --fp8
 done
 python3 - <<PY
 import csv, glob, json, statistics
 out = {}
 for sh in ("o", "gate_up"):
-  for tag in ("nv", "mx", "hbl_first", "hbl_best"):
+  for tag in ("nv", "mx", "hbl_first", "hbl_best", "native_mx_mxfp8", "native_nv_mxfp8", "native_mx_mxfp4", "hbl_fp8"):
     t = f"{sh}_{tag}"
     vals, dur, name = {}, [], None
     for f in glob.glob("$OUT/pmc_%s/**/*counter_collection.csv" % t, recursive=True):
@@ -60,4 +65,4 @@ for k, v in out.items():
     print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if a != "counters"})
 PY
 cd $R
-python3 tools/power_probe.py --m $M --shapes o,gate_up --no-native --seconds 2.0 --out $OUT/power_probe_m$M.json 2>&1 | tail -20
+python3 tools/power_probe.py --m $M --shapes o,gate_up --seconds 2.0 --out $OUT/power_probe_m$M.json 2>&1 | tail -24

@@ -16,9 +16,11 @@ cd /tmp
 # (native: the FP4 x FP4 32x32x64 kernel the class table picks on gate_up: 128x256, two workgroups per CU, two k-tiles per stage, two stages ahead)
 # (native8: the FP4 x FP8 kernel of round 4 on the same shape: 128x256, lean fragments, two workgroups per CU)
 # (native6: the FP4 x FP6 kernel on the same shape: MXFP6 e2m3 activations, 128x256, lean fragments, two workgroups per CU)
-for v in "nv tiled" "mx native" "mx native8" "mx native6"; do
+# (nvnative8 / nvnative6, round 6: NVFP4 weights on their MFMA-native image through the class sentinels, MXFP8 / MXFP6 activations)
+for v in "nv tiled" "mx native" "mx native8" "mx native6" "nv nvnative8" "nv nvnative6"; do
   set -- $v
   EXTRA=""; [ "$2" = "native" ] && EXTRA="--native --solution 124da41623301004"; [ "$2" = "native8" ] && EXTRA="--native --solution 124d541223101004"; [ "$2" = "native6" ] && EXTRA="--native --solution 124d541423501004"
+  [ "$2" = "nvnative8" ] && EXTRA="--sentinel mxfp8"; [ "$2" = "nvnative6" ] && EXTRA="--sentinel mxfp6"
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_mfma_$2_${TAG} -o p -- python3 $R/tools/profile_one.py --m 512 --n 57344 --k 8192 --fmt $1 $EXTRA --iters 20 > $R/gpurun_out/pmc_mfma_$2_${TAG}.log 2>&1
 done
 cd $R

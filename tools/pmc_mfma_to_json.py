@@ -15,7 +15,7 @@ out = {"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BU
                   "-- python3 tools/profile_one.py --m 512 --n 57344 --k 8192 --fmt nv|mx [--native] --iters 20 (tools/collect_profiles.sh)",
        "notes": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); kernel times under PMC are 10-40 % longer than in the "
                 "sweeps and the clock lower (never compare a profiled run with an un-profiled one)"}
-for kind in ("tiled", "native", "native8", "native6"):
+for kind in ("tiled", "native", "native8", "native6", "nvnative8", "nvnative6"):
     vals, dur, names = {}, [], set()
     for f in glob.glob(str(ROOT / f"gpurun_out/pmc_mfma_{kind}_{tag}/**/*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -35,4 +35,4 @@ for kind in ("tiled", "native", "native8", "native6"):
                  "valu_per_mfma": med.get("SQ_INSTS_VALU", 0) / med["SQ_INSTS_MFMA"] if med.get("SQ_INSTS_MFMA") else None,
                  "effective_clock_ghz": cyc / statistics.median(dur) if dur else None}
 (ROOT / f"profiles/{tag}_pmc_mfma.json").write_text(json.dumps(out, indent=1))
-print(json.dumps({k: (v if not isinstance(v, dict) else {kk: v[kk] for kk in ("kernel", "mfma_util", "valu_per_mfma", "effective_clock_ghz", "kernel_ns_median_under_pmc")}) for k, v in out.items() if k in ("tiled", "native", "native8", "native6")}, indent=1))
+print(json.dumps({k: (v if not isinstance(v, dict) else {kk: v[kk] for kk in ("kernel", "mfma_util", "valu_per_mfma", "effective_clock_ghz", "kernel_ns_median_under_pmc")}) for k, v in out.items() if k in ("tiled", "native", "native8", "native6", "nvnative8", "nvnative6")}, indent=1))

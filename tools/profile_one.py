@@ -23,6 +23,7 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--solution", default="auto")
 ap.add_argument("--fmt", default="nv")
 ap.add_argument("--native", action="store_true", help="mx only: run the fastest-looking native-FP4 kernel (largest tile)")
+ap.add_argument("--sentinel", default="", help="mxfp8 / mxfp6 / mxfp4: the native class's default pick (NVFP4 weights: on their MFMA-native image, built and attached here)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 n, k, m = a.n, a.k, a.m
@@ -43,6 +44,18 @@ gs = torch.ones(1, device=dev)
 hints = _lib.SolutionHints(_lib.CXX_DTYPE_BF16, _lib.CXX_DTYPE_FP4_E2M1 if a.fmt == "nv" else _lib.CXX_DTYPE_MXFP4_E2M1,
                            _lib.CXX_DTYPE_BF16, 0)
 sid = _lib.PETIT_SOLUTION_AUTO if a.solution == "auto" else int(a.solution, 16)
+images = []
+if a.sentinel:
+    sid = {"mxfp8": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8, "mxfp6": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP6, "mxfp4": _lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP4}[a.sentinel]
+    if a.fmt == "nv":
+        nbytes = int(_lib.lib.petit_nvfp4_native_image_bytes(k, n))
+        for b, sp in packed:
+            img = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            assert _lib.lib.petit_nvfp4_native_image(C.c_void_p(img.data_ptr()), C.c_void_p(b.data_ptr()), C.c_void_p(sp.data_ptr()), k, n, None) == 0
+            assert _lib.lib.petit_nvfp4_native_attach(C.c_void_p(b.data_ptr()), C.c_void_p(img.data_ptr())) == 0
+            images.append(img)
+        torch.cuda.synchronize()
+    print("native class pick", hex(int(_lib.lib.petit_gemm_resolve_solution(C.byref(hints), m, n, k, C.c_uint64(sid), None, C.c_uint64(1 << 62)))))
 ws = None
 if a.native:
     _lib.lib.petit_enable_native_fp4(1)
