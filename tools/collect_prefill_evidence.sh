@@ -66,3 +66,10 @@ for k, v in out.items():
 PY
 cd $R
 python3 tools/power_probe.py --m $M --shapes o,gate_up --seconds 2.0 --out $OUT/power_probe_m$M.json 2>&1 | tail -24
+# the group-ahead kernel and its MFMA-only skeleton (tools/ablate_wide.sh 47 must have been built): is a bare bf16 MFMA stream power-capped?
+for abl in shipped 47 4; do
+  if [ $abl = shipped ]; then unset PETIT_AMD_LIB; else export PETIT_AMD_LIB=$R/tools/ablate/wide/libpetit_abl_$abl.so; fi
+  [ $abl = shipped ] || [ -f "$PETIT_AMD_LIB" ] || continue
+  python3 tools/power_probe.py --m $M --shapes o --nv-solution 124c146113101008 --seconds 2.0 --out $OUT/power_probe_ga256_abl$abl.json 2>&1 | tail -1
+done
+unset PETIT_AMD_LIB

@@ -2,7 +2,7 @@
 """tools/fuzz_parity.py [seed] [seconds] -- random problems against the oracle through the public Python surface (needs an MI355X).
 
 Draws (weight format, activation dtype, M, N, K) from lists that cover every span size (K % 1024 / 512 / 256), ragged M and N, every M bucket, and one of
-six call forms: solution_id = -1 plain / with a bias / with the SiLU-mul epilogue, and -- MXFP4 weights -- the three native classes through their sentinels
+six call forms: solution_id = -1 plain / with a bias / with the SiLU-mul epilogue, and the three native classes through their sentinels (MXFP4 weights raw; NVFP4 weights on their attached image)
 (checked for exact semantics against the oracle run on the CPU-quantised activations).  Bounds and helpers are the test suite's own (tests/test_gpu_parity.py).
 Prints every failure with its margin (error / bound) and a summary line; profiles/r04_fuzz.txt is such a log."""
 import sys, numpy as np, torch, time
@@ -21,7 +21,8 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
     m = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 44, 48, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 300, 511, 512, 513, 600, 700, 1024, 1100, 1500, 2084, 2200]))   # (the last five: ragged prefill M, bulk + tail launches)
     if m * n * k > 4e9: continue
     a, q, s, gs = T.random_problem(kind, m, n, k, int(rng.integers(1 << 30)), is_bf16)
-    mode = rng.choice(["auto", "explicit", "explicit", "bias", "silu", "fp6", "fp8", "fp4"]) if kind == "mx" else rng.choice(["auto", "explicit", "explicit", "bias", "silu"])
+    # (round 6: NVFP4 weights take the native classes too -- on their MFMA-native image, through the attached-weights route of the reference's entry point)
+    mode = rng.choice(["auto", "explicit", "explicit", "bias", "silu", "fp6", "fp8", "fp4"])
     try:
         if m <= 16 and rng.random() < 0.25:    # a grouped launch: 2-4 weight matrices of random N on the same activation rows
             mode = "grouped"
@@ -87,11 +88,28 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 150:
                 fmt = {"fp6": "mxfp6", "fp8": "mxfp8", "fp4": "mxfp4"}[mode]
                 quant = {"mxfp6": T.quantize_act_mxfp6, "mxfp8": T.quantize_act_mxfp8, "mxfp4": T.quantize_act_mxfp4}[fmt]
                 a_q = quant(T.to_f32(a, is_bf16))
-                dq = T.O.dequant_mxfp4(q, s)
+                dq = T.O.dequant_mxfp4(q, s) if kind == "mx" else T.O.nv6_reencode(q, s)[0]     # (NVFP4: the image's values)
                 _, exact = T.O.gemm_ref(T.O.f32_to_bf16_bits(a_q), True, dq, gs)
                 sum_abs = (np.abs(T.to_f32(a, is_bf16)) @ np.abs(dq).T) * gs
-                c = pk.mul_mxfp4_native(ad, b, sp, gsd, m, n, k, T.NATIVE_SENTINEL(pk, fmt))
+                if kind == "mx":
+                    c = pk.mul_mxfp4_native(ad, b, sp, gsd, m, n, k, T.NATIVE_SENTINEL(pk, fmt))
+                else:
+                    image = pk.nvfp4_native_image(b, sp, n, k)
+                    pk.attach_nvfp4_native(b, image)
+                    try:
+                        c = pk.mul_nvfp4_a16(ad, b, sp, gsd, m, n, k, T.NATIVE_SENTINEL(pk, fmt))
+                    finally:
+                        pk.attach_nvfp4_native(b, None)
                 got = T.to_f32(T.bits(c), is_bf16).astype(np.float64)
+                # a ragged prefill M may run as bulk (in the class) + a short tail through the exact default pick (petit_gemm_row_split): tail rows against the exact oracle
+                hh = pk.PetitSolutionHints(); hh.a_type = hh.c_type = torch.bfloat16 if is_bf16 else torch.float16
+                hh.b_type = pk.DataType.float4_e2m1 if kind == "nv" else pk.DataType.mxfloat4_e2m1
+                m1 = pk.ops.auto_row_split(hh, m, n, k, solution_id=T.NATIVE_SENTINEL(pk, fmt))
+                if m1:
+                    dq_true = T.O.dequant_mxfp4(q, s) if kind == "mx" else T.O.dequant_nvfp4(q, s)
+                    _, tail_ref = T.O.gemm_ref(a[m1:], is_bf16, dq_true, gs)
+                    T.check_gemm(T.bits(c[m1:]), tail_ref, is_bf16, (np.abs(T.to_f32(a[m1:], is_bf16)) @ np.abs(dq_true).T) * gs if kind == "mx" else None)
+                    got, exact, a_q, sum_abs = got[:m1], exact[:m1], a_q[:m1], sum_abs[:m1]
                 fin = np.isfinite(exact) & (np.abs(exact) < (3e38 if is_bf16 else 6e4))
                 err = np.abs(got - exact)[fin]
                 bound = np.maximum(np.maximum(1e-2, 1e-2 * np.abs(exact)), T.native_exact_bound(a_q, dq, gs, fmt))[fin]   # (as the tests: derived from the instruction)
