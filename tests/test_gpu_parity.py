@@ -3001,10 +3001,10 @@ def test_stacked_mlp_accuracy_budget_checkpoint_like_weights(pk, wfmt):
 
 
 def test_examples_run(pk):
-    """examples/fp4_linear.py and examples/mxfp4_mlp_pipeline.py run to completion on the GPU (their own assertions included)."""
+    """examples/fp4_linear.py, examples/mxfp4_mlp_pipeline.py and examples/nvfp4_native_prefill.py run to completion on the GPU (their own assertions included)."""
     import subprocess
     import sys
-    for name in ("fp4_linear.py", "mxfp4_mlp_pipeline.py"):
+    for name in ("fp4_linear.py", "mxfp4_mlp_pipeline.py", "nvfp4_native_prefill.py"):
         out = subprocess.run([sys.executable, str(ROOT / "examples" / name)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "MISMATCH" not in out.stdout
