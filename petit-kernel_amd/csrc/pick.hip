@@ -174,7 +174,9 @@ AutoChoice choose_auto(const Family &fam, int dev, int a_type, int b_type, bool 
                 hi = alt[i].m_hi;
         const unsigned rep = hi == 0 ? m : hi > 4096 ? 8192u : hi == 4096 ? 2048u : hi; // the M the row was measured at (tools/make_tuned_inc.py BUCKET)
         const double own = waste(*c.entry, m);
-        if (own > 1.08 * waste(*c.entry, rep)) {
+        // (round 6: not when the bulk + tail plan fires for the row's OWN kernel -- its bulk is whole rounds of the measured winner again; a sibling is the
+        // second-best kernel of another M.  `o` at M = 4314, NVFP4: the 256 x 256 row -> 4096 rows in two full rounds + 218 rows of batched decode)
+        if (own > 1.08 * waste(*c.entry, rep) && plan_row_split(*c.entry, 1, m, n, k, num_cus) == 0) {
             double best_w = own;
             for (int i = 0; i < n_alt; ++i) {
                 if (alt[i].m_hi <= 512 || solution_splitk(alt[i].solution) != 1)
