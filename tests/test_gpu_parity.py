@@ -1189,7 +1189,7 @@ class FullSizeProblem:
         k, n = self.k, self.n
         zero = torch.zeros((m, k), dtype=dtype, device=DEV)
         assert torch.count_nonzero(self.mul(zero, self.b, self.sp, torch.ones(1, device=DEV), m, n, k, sid)) == 0
-        cols = [0, 31, 32, 127, 128, 1023, 1024, k // 2 + 17, k - 1][:m]
+        cols = sorted({c_ for c_ in (0, 31, 32, 127, 128, 1023, 1024, k // 2 + 17, k - 1) if c_ < k})[:m]
         onehot = torch.zeros((m, k), dtype=dtype, device=DEV)
         for i, c_ in enumerate(cols):
             onehot[i, c_] = 1.0

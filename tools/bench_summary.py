@@ -5,7 +5,7 @@ import sys
 
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 d20 = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]) if len(sys.argv) > 2 else None
-PEAK = {"hipblaslt_fp8": 5000.0, "native_mxfp8": 5000.0, "native_mxfp6": 10000.0, "native_mxfp4": 10000.0, "mlp_native_mxfp8_pipeline": 5000.0}
+PEAK = {"hipblaslt_fp8": 5000.0, "hipblaslt_fp8_best": 5000.0, "native_mxfp8": 5000.0, "native_mxfp6": 10000.0, "native_mxfp4": 10000.0, "mlp_native_mxfp8_pipeline": 5000.0}
 
 
 def expand(d):
@@ -20,7 +20,7 @@ def expand(d):
             for m, u, r in zip(d["cells_m"][dt], us, rates):
                 if u is None:
                     continue
-                hbm = m <= 64 and shape != "mlp"
+                hbm = (m <= 64 and shape != "mlp") or shape == "tp8_layer"
                 mode = dt.split()[-1] if " " in dt else ""
                 peak = 8000.0 if hbm else PEAK.get(mode, 10000.0 if mode.startswith("mlp_native") else 2500.0)
                 out.append({"shape": shape, "M": m, "dt": dt, "us": u, "frac": r / peak, "GBs" if hbm else "TF": r})
@@ -46,7 +46,8 @@ for s in shapes:
                                    for dt, m in cols) + " |")
 print("\nM = 512 (TFLOP/s; fraction of 2.5 PF bf16 peak, native: of the 5 / 10 PF FP8 / FP4 peaks; native cells include the activation-quantiser launch):\n")
 cols = [("bf16xnv", "bf16 x NVFP4"), ("fp16xnv", "fp16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("fp16xmx", "fp16 x MXFP4"), ("bf16xmx native_mxfp8", "native, act -> MXFP8 (-2)"), ("bf16xmx native_mxfp6", "native, act -> MXFP6 (-4)"),
-        ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xdense hipblaslt", "hipBLASLt bf16 dense"), ("fp8xdense hipblaslt_fp8", "hipBLASLt FP8 dense")]
+        ("bf16xmx native_mxfp4", "native, act -> MXFP4 (-3)"), ("bf16xnv native_mxfp8", "NVFP4 image x MXFP8 (-2)"), ("bf16xnv native_mxfp6", "NVFP4 image x MXFP6 (-4)"), ("bf16xnv native_mxfp4", "NVFP4 image x MXFP4 (-3)"),
+        ("bf16xdense hipblaslt", "hipBLASLt bf16 dense"), ("fp8xdense hipblaslt_fp8", "hipBLASLt FP8 dense")]
 print("| shape | " + " | ".join(name for _, name in cols) + " |")
 print("|---|" + "---|" * len(cols))
 for s in shapes:
@@ -65,7 +66,8 @@ pre = sorted({k[1] for k in cells if k[1] > 512})
 if pre:
     print("\nPrefill (M > 512; TFLOP/s, native cells include the activation-quantiser launch):\n")
     cols = [("bf16xnv", "bf16 x NVFP4"), ("bf16xmx", "bf16 x MXFP4"), ("bf16xmx native_mxfp8", "native MXFP8"), ("bf16xmx native_mxfp6", "native MXFP6"),
-            ("bf16xmx native_mxfp4", "native MXFP4"), ("bf16xdense hipblaslt", "hipBLASLt bf16"), ("fp8xdense hipblaslt_fp8", "hipBLASLt FP8")]
+            ("bf16xmx native_mxfp4", "native MXFP4"), ("bf16xnv native_mxfp8", "NVFP4 image x MXFP8"), ("bf16xnv native_mxfp6", "NVFP4 image x MXFP6"), ("bf16xnv native_mxfp4", "NVFP4 image x MXFP4"),
+            ("bf16xdense hipblaslt", "hipBLASLt bf16"), ("bf16xdense hipblaslt_best", "hipBLASLt bf16, best of the heuristic's results"), ("fp8xdense hipblaslt_fp8", "hipBLASLt FP8"), ("fp8xdense hipblaslt_fp8_best", "hipBLASLt FP8, best")]
     print("| shape | M | " + " | ".join(name for _, name in cols) + " |")
     print("|---|---|" + "---|" * len(cols))
     for s in shapes:
@@ -79,9 +81,22 @@ if big:
     m_big = max(k[1] for k in big)
     print(f"\nfp16 x MXFP4 at M = {m_big} (the family x regime of round 5's tuner-check bug): " +
           ", ".join(f"{s} {cells[(s, m_big, 'fp16xmx')]['us']:.0f} us = {cells[(s, m_big, 'fp16xmx')]['TF']:.0f} TFLOP/s" for s in shapes if (s, m_big, "fp16xmx") in cells) + ".")
+tp8 = ["tp8_qkv", "tp8_o", "tp8_gate_up", "tp8_down"]
+if any(k[0] in tp8 for k in cells):
+    print("\nTP = 8 shard shapes (bf16 x NVFP4, solution_id = -1; M <= 64: us, fraction of 8 TB/s; M = 512: us, TFLOP/s) -- qkv 1280 x 8192, o 8192 x 1024, gate_up 7168 x 8192, down 8192 x 3584:\n")
+    ms = sorted({k[1] for k in cells if k[0] in tp8})
+    print("| shape | " + " | ".join(f"M={m}" for m in ms) + " |")
+    print("|---|" + "---|" * len(ms))
+    for s in tp8:
+        def fmt(c):
+            return f"{c['us']:.2f} us, {c['frac']:.2f}" if "GBs" in c else f"{c['us']:.1f} us, {c['TF']:.0f} TF"
+        print(f"| {s} | " + " | ".join(fmt(cells[(s, m, 'bf16xnv')]) if (s, m, "bf16xnv") in cells else "-" for m in ms) + " |")
+    for (s, m, dt), c in cells.items():
+        if s == "tp8_layer":
+            print(f"\nOne decode layer's four launches at TP = 8 (grouped q / k / v -> o -> gate_up + SiLU-mul -> down), M = {m}: {c['us']:.2f} us = {c['GBs']:.0f} GB/s of algorithmic bytes = {c['frac']:.2f} of 8 TB/s.")
 print("\nLaunch-gap-bound shapes and the MLP block:\n\n| cell | us | rate |\n|---|---|---|")
 for (s, m, dt), c in cells.items():
-    if s.startswith("tp8"):
+    if s == "tp8_qkv_3x1280":
         print(f"| three 1280 x 8192 shards, M = {m}, {dt.split()[-1]} | {c['us']:.2f} | {c['GBs']} GB/s |")
     elif s == "mlp":
         print(f"| Llama-70B MLP block M = 512, {dt.split()[-1].replace('mlp_', '')} | {c['us']:.1f} | {c['TF']:.0f} TFLOP/s |")
