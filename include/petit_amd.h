@@ -172,7 +172,7 @@ uint64_t petit_gemm_resolve_solution(const petit_solution_hints *hints, unsigned
                                      const petit_epilogue *epilogue, uint64_t workspace_bytes);
 /* Rows are independent, so a default-pick call (PETIT_SOLUTION_AUTO, exact class) at a prefill M whose tile grid ends a little past a
  * whole number of rounds of the chip runs as TWO launches on the caller's stream: the first `rows` rows with the kernel picked for them
- * (a grid of whole rounds), the remaining m - rows rows as a default-pick problem of their own (petit-kernel_amd/csrc/api.hip
+ * (a grid of whole rounds), the remaining m - rows rows as a default-pick problem of their own (petit-kernel_amd/csrc/pick.hip
  * plan_row_split; petit_gemm_workspace_bytes covers both).  Returns `rows`, or 0 when the call runs as one launch (always for explicit
  * ids, the native class, m <= 512, $PETIT_AMD_NO_ROW_SPLIT=1).  petit_gemm_default_solution / _resolve_solution name the kernel of
  * the problem as a whole; resolve them at (rows) and (m - rows) for the two launches.  No reference counterpart: the reference's

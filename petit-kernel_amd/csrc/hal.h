@@ -54,7 +54,7 @@ uint64_t tuned_solution(int device, int a_type, int b_type, unsigned m, unsigned
 uint64_t tuned_nearest(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, unsigned *n_found = nullptr,
                        unsigned *k_found = nullptr);
 // The `cap` nearest tabulated shapes (one entry per shape, nearest first, each with the row that holds m), for callers that want to rank them:
-// api.hip choose_auto scores the neighbours' kernels for THIS problem's grid instead of taking the nearest blindly.
+// pick.hip choose_auto scores the neighbours' kernels for THIS problem's grid instead of taking the nearest blindly.
 struct TunedNeighbour {
     uint64_t solution;
     unsigned n, k;
@@ -62,7 +62,7 @@ struct TunedNeighbour {
 };
 int tuned_nearest_list(int device, int a_type, int b_type, unsigned m, unsigned n, unsigned k, int klass, double max_distance, TunedNeighbour *out, int cap);
 // Every built-in / run-time row of ONE tabulated shape and class (all M buckets), for callers that want to weigh a bucket's row against its neighbours'
-// (api.hip choose_auto: tile quantisation at a ragged prefill M).  Returns the count written (<= cap).
+// (pick.hip choose_auto: tile quantisation at a ragged prefill M).  Returns the count written (<= cap).
 int tuned_shape_rows(int device, int a_type, int b_type, unsigned n, unsigned k, int klass, TunedEntry *out, int cap);
 // class of a solution id: 0 exact, 8 / 4 native with MXFP8 / MXFP4 activations
 int solution_class(uint64_t solution);

@@ -78,7 +78,7 @@ const TunedEntry kBuiltinNative[] = {
 };
 
 // rows from $PETIT_AMD_TUNE_FILE (read once) and rows added at run time, newest first; guarded by g_rows_mutex (the lookup
-// runs only when a thread's default-pick cache misses, api.hip choose_auto)
+// runs only when a thread's default-pick cache misses, pick.hip choose_auto)
 std::vector<TunedEntry> g_override;
 std::once_flag g_override_once;
 std::mutex g_rows_mutex;

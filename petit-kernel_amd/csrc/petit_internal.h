@@ -79,7 +79,7 @@ struct GroupTable {
     const void *bias[kMaxGroup];
 };
 
-// api.hip: the dispatcher behind every GEMM entry point (solution_id: explicit id or one of the AUTO sentinels)
+// dispatch.hip: the dispatcher behind every GEMM entry point (solution_id: explicit id or one of the AUTO sentinels)
 } // namespace petit_amd
 struct petit_solution_hints;
 struct petit_epilogue;

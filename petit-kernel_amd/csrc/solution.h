@@ -51,7 +51,7 @@
 namespace petit_amd {
 
 enum : unsigned { kFeatGrid = 1u, kFeatHighPrecision = 2u };
-enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u }; // (3 was round 3's "MXFP4, scales promised in fp16's range": read as 2 now, find_explicit in api.hip)
+enum : unsigned { kElemBNvFp4 = 1u, kElemBMxFp4 = 2u }; // (3 was round 3's "MXFP4, scales promised in fp16's range": read as 2 now, find_explicit in solutions.hip)
 enum : unsigned { kMfmaFp16 = 0u, kMfmaBf16 = 1u, kMfmaFp8 = 2u, kMfmaFp8ActFp16 = 2u | 8u, kMfmaFp4 = 6u, kMfmaFp4ActFp16 = 6u | 8u, kMfmaFp6 = 4u, kMfmaFp6ActFp16 = 4u | 8u };
 
 struct StreamShape {
@@ -115,7 +115,7 @@ struct SolutionEntry {
     LaunchGroupedFn launch_grouped = nullptr; // the decode and the staged streaming kernels have one (M <= 16)
 };
 
-// one table per (activation type, weight format) family, concatenated once (api.hip) from the parts its translation units export
+// one table per (activation type, weight format) family, concatenated once (solutions.hip) from the parts its translation units export
 // (stream_tu.inc: gemm_<family>_p<part>.hip)
 const SolutionEntry *solutions_nv_bf16(int *count);
 const SolutionEntry *solutions_nv_f16(int *count);

@@ -11,7 +11,7 @@
 // the 256 MB Infinity Cache cannot serve them (the caller passes the copies, or the tuner clones the caller's one copy
 // into a rotation of its own); one untimed sample first; median of `samples` hipEvent-timed samples; a candidate whose first
 // sample is 1.5x behind the leader is dropped early.  A candidate is only timed after its output matched the class's
-// reference kernel (api.hip tune_candidates) element by element: a kernel that miscomputes at this shape is never ranked.
+// reference kernel (dispatch.hip tune_candidates) element by element: a kernel that miscomputes at this shape is never ranked.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

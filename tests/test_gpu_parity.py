@@ -277,7 +277,7 @@ def test_random_vs_oracle_default_solution(pk, kind, is_bf16, m, n, k):
     check_gemm(c, oracle_ref(kind, a, is_bf16, q, s, gs), is_bf16, oracle_sum_abs(kind, a, is_bf16, q, s, gs))
 
 
-# shapes NO table knows, each within reach of a tabulated one (api.hip kNearestMaxDistance): solution_id = -1 runs the kernel the arch table names
+# shapes NO table knows, each within reach of a tabulated one (pick.hip kNearestMaxDistance): solution_id = -1 runs the kernel the arch table names
 # for the NEAREST tabulated shape (hal.hip tuned_nearest) -- kernels picked for another N / K, K splits sized for another span count, 224- and
 # 320-column tiles on an N they do not divide
 UNSEEN_SHAPES = [(1, 5152, 5120), (8, 7232, 2304), (16, 4192, 13312), (24, 8160, 7936), (32, 10400, 8704), (48, 3616, 4352), (64, 8192, 7168),
