@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_row_split.py [seed] [seconds] [native] -- random prefill problems on which a default-pick call runs as bulk + tail (csrc/api.hip plan_row_split), against the oracle.
+"""tools/fuzz_row_split.py [seed] [seconds] [native] -- random prefill problems on which a default-pick call runs as bulk + tail (csrc/pick.hip plan_row_split), against the oracle.
 
 tools/fuzz_parity.py checks every output of its problems and therefore keeps M N K below 4e9, where a tile grid never reaches a whole round of the chip; here the shapes are
 prefill-sized (N 2048-16384, K 2048-8192, M 513-4500, all four dtype families, plain / bias / SiLU-mul epilogues) and the oracle checks a SAMPLE: the rows around the split,

@@ -1,13 +1,17 @@
 #!/bin/bash
 # tools/pmc_stalls.sh <tag> <solution-hex> [fmt] [m n k] -- stall breakdown of one kernel under rocprofv3 --pmc (two passes of
-# 8 SQ counters; separate from any trace domain, as the pool requires).  Output: gpurun_out/pmc_stall_<tag>_{a,b}/
+# 8 SQ counters; separate from any trace domain, as the pool requires).  <solution-hex> may be sentinel:mxfp8 | sentinel:mxfp6 | sentinel:mxfp4 (the native class's
+# default pick; NVFP4 weights on their attached image); $PMC_EXTRA is appended to profile_one.py's arguments (e.g. --native for an explicit native id).
+# Output: gpurun_out/pmc_stall_<tag>_{a,b}/
 R=$(cd "$(dirname "$0")/.." && pwd)
 TAG=$1; SOL=$2; FMT=${3:-nv}; M=${4:-512}; N=${5:-57344}; K=${6:-8192}
+case $SOL in sentinel:*) SOLARG="--sentinel ${SOL#sentinel:}";; *) SOLARG="--solution $SOL";; esac
+SOLARG="$SOLARG ${PMC_EXTRA:-}"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS \
-  --output-format csv -d $R/gpurun_out/pmc_stall_${TAG}_a -o p -- python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt $FMT --solution $SOL --iters 12 > $R/gpurun_out/pmc_stall_${TAG}_a.log 2>&1
+  --output-format csv -d $R/gpurun_out/pmc_stall_${TAG}_a -o p -- python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt $FMT $SOLARG --iters 12 > $R/gpurun_out/pmc_stall_${TAG}_a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU GRBM_GUI_ACTIVE \
-  --output-format csv -d $R/gpurun_out/pmc_stall_${TAG}_b -o p -- python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt $FMT --solution $SOL --iters 12 > $R/gpurun_out/pmc_stall_${TAG}_b.log 2>&1
+  --output-format csv -d $R/gpurun_out/pmc_stall_${TAG}_b -o p -- python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt $FMT $SOLARG --iters 12 > $R/gpurun_out/pmc_stall_${TAG}_b.log 2>&1
 python3 - <<PY
 import csv, statistics, glob, json
 out = {}
@@ -26,7 +30,7 @@ open("$R/gpurun_out/pmc_stall_${TAG}.json", "w").write(json.dumps(out, indent=1)
 PY
 # third pass: L2 behaviour of the same launches
 cd /tmp
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum --output-format csv -d $R/gpurun_out/pmc_stall_${TAG}_c -o p -- python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt $FMT --solution $SOL --iters 12 > $R/gpurun_out/pmc_stall_${TAG}_c.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum --output-format csv -d $R/gpurun_out/pmc_stall_${TAG}_c -o p -- python3 $R/tools/profile_one.py --m $M --n $N --k $K --fmt $FMT $SOLARG --iters 12 > $R/gpurun_out/pmc_stall_${TAG}_c.log 2>&1
 python3 - <<PY
 import csv, statistics, glob, json
 vals = {}
