@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""tools/adopt_rows.py --log NEW.csv[.gz] [--confirm OLD.csv[.gz]] [--ms 32,64] --out rows.tune.txt -- which rows of csrc/tuned_gfx950.inc a tuning session may replace.
+"""tools/adopt_rows.py --log NEW.csv[.gz] [--confirm OLD.csv[.gz]] [--ms 32,64] [--klass 8|6|4] --out rows.tune.txt -- which rows of csrc/tuned_gfx950.inc (with --klass: of
+csrc/tuned_native_gfx950.inc, the class whose activations are MXFP8 / MXFP6 / MXFP4) a tuning session may replace.
 
 The in-library tuner's per-candidate log ($PETIT_AMD_TUNE_LOG, tools/build_table.py) times the table's current pick and every challenger in ONE session.  A row is
 replaced only when (single-session timings sit inside the noise the picks are made on)
@@ -24,18 +25,22 @@ def main():
     ap.add_argument("--confirm", default="")
     ap.add_argument("--ms", default="")
     ap.add_argument("--out", required=True)
-    ap.add_argument("--table", default=str(ROOT / "petit-kernel_amd" / "csrc" / "tuned_gfx950.inc"))
+    ap.add_argument("--table", default="")
+    ap.add_argument("--klass", type=int, default=0, choices=[0, 8, 6, 4], help="0: the exact class; 8 / 6 / 4: the native class with MXFP8 / MXFP6 / MXFP4 activations")
     a = ap.parse_args()
+    a.table = a.table or str(ROOT / "petit-kernel_amd" / "csrc" / ("tuned_native_gfx950.inc" if a.klass else "tuned_gfx950.inc"))
+    act_code = {0: None, 8: 2, 6: 4, 4: 6}[a.klass]       # bits 32-34 of a native id
     b2, c2 = read(a.log)
     c1 = read(a.confirm)[1] if a.confirm else {}
     ms = {int(x) for x in a.ms.split(",")} if a.ms else None
     rows = {}
     for at, bt, n, k, lo, hi, sol in re.findall(r"\{(\d+), (\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, 0x([0-9a-f]+)ull\}", Path(a.table).read_text()):
-        rows.setdefault((int(at), int(bt), int(n), int(k)), []).append((int(lo), int(hi), int(sol, 16)))
+        if act_code is None or (int(sol, 16) >> 32) & 7 == act_code:
+            rows.setdefault((int(at), int(bt), int(n), int(k)), []).append((int(lo), int(hi), int(sol, 16)))
     out, gains, kept, two, one = [], [], 0, 0, 0
     for key in sorted(b2):
         at, bt, klass, m, n, k = key
-        if klass or (ms and m not in ms):
+        if klass != a.klass or (ms and m not in ms):
             continue
         old = [s for lo, hi, s in rows.get((at, bt, n, k), []) if lo <= m <= hi]
         o2 = c2[key].get(old[0]) if old else None
