@@ -8,7 +8,7 @@ next to it, hipBLASLt's 16-bit dense GEMM of the same size (first heuristic resu
 One JSON line per problem; `--md` turns a log into the table of profiles/rNN_reference_list.md.
 
     python tools/reference_list_sweep.py --out gpurun_out/r06_reference_list.jsonl [--atype fp16] [--btype nv] [--native]
-    python tools/reference_list_sweep.py --md gpurun_out/r06_reference_list.jsonl > profiles/r06_reference_list.md
+    python tools/reference_list_sweep.py --md a.jsonl[,b.jsonl] > profiles/r06_reference_list.md
 """
 import argparse
 import json
@@ -100,7 +100,9 @@ def sweep(args):
 
 
 def table(path):
-    recs = [json.loads(x) for x in open(path) if x.strip().startswith("{")]
+    recs = [json.loads(x) for one in path.split(",") for x in open(one) if x.strip().startswith("{")]
+    order = {(m, n, k): i for i, (m, n, k) in enumerate(sorted(problems(), key=lambda p: (p[0], family(p[1], p[2]), p[1], p[2])))}
+    recs.sort(key=lambda r: order[(r["m"], r["n"], r["k"])])
     dts = sorted({r["dt"] for r in recs})
     print("# The reference's benchmark list (tools/benchmarks/matmul.py:8-117), every entry, on one MI355X\n")
     print("`python tools/reference_list_sweep.py`: solution_id = -1 through the C ABI, graph-replayed launches over rotating weight copies (tools/benchlib.py); hipBLASLt = its 16-bit dense GEMM of the same "
