@@ -1018,3 +1018,19 @@ def test_nv6_entry_points_validate_without_a_gpu():
     rc = L.petit_gemm_fp4_fp16_grid_ws(C.addressof(buf), C.addressof(buf), C.addressof(buf), C.addressof(buf), C.addressof(buf), 64, 64, 256, C.byref(h),
                                        C.c_uint64(_lib.PETIT_SOLUTION_AUTO_NATIVE_MXFP8), None, None, 0, None)
     assert rc == _lib.PETIT_ERROR_KERNEL_SHAPE
+
+
+def test_reference_benchmark_list_is_restated_whole():
+    """tools/reference_list_sweep.py restates the reference's benchmark problems by shape family (tools/benchmarks/matmul.py:8-117): 104 distinct (m, n, k), the
+    reference's M values, every one inside the library's range and with a default pick; where the reference tree is present (the build container), the same multiset."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import reference_list_sweep as RL
+    probs = RL.problems()
+    assert len(probs) == 104 and len(set(probs)) == 104
+    assert sorted({m for m, _, _ in probs}) == [15, 16, 44, 256, 512, 566, 582, 611, 874, 932, 1003, 1324, 1340, 1466, 1906, 2084, 4314, 14437, 15961, 16375]
+    assert all(n % 16 == 0 and k % 256 == 0 for _, n, k in probs)
+    ref = Path("/root/reference/tools/benchmarks/matmul.py")
+    if ref.exists():
+        listed = [tuple(int(x) for x in t) for t in re.findall(r"\((\d+), (\d+), (\d+)\),", ref.read_text())]
+        assert sorted(listed) == sorted(probs)
