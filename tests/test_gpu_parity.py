@@ -1614,6 +1614,49 @@ def test_auto_row_split_matches_oracle(pk):
     assert ran >= 2
 
 
+def test_native_row_split_is_its_two_parts_and_is_capturable(pk):
+    """The native class at a ragged prefill M (csrc/pick.hip plan_row_split_native): the call's bulk rows are bit for bit what the class computes on a problem of
+    those rows alone, its tail rows bit for bit what the EXACT default pick computes on the tail alone (never another accuracy class, never a different kernel than the
+    queries name), and the whole call -- quantiser + class kernel + exact kernel -- replays from a HIP graph to the same bits."""
+    ran = 0
+    for kind in ("nv", "mx"):
+        n, k, m = 8192, 8192, 2084
+        P = FullSizeProblem(pk, kind, n, k, 9100 + len(kind))
+        h = P.hints(True)
+        for sid in (pk.SOLUTION_AUTO_NATIVE_MXFP8, pk.SOLUTION_AUTO_NATIVE_MXFP4):
+            if kind == "nv":
+                _ = P.image
+            m1 = pk.ops.auto_row_split(h, m, n, k, solution_id=sid)
+            if not m1:
+                continue   # (the class table changed under this case)
+            assert 0 < m - m1 <= 128 and pk.ops.auto_row_split(h, m1, n, k, solution_id=sid) == 0
+            a = P.activations(m, True, 9200)
+            c = P.run(a, True, sid)
+            bulk = P.run(a[:m1], True, sid)
+            tail = P.run(a[m1:], True, -1)
+            assert torch.equal(c[:m1].view(torch.int16), bulk.view(torch.int16)), (kind, sid)
+            assert torch.equal(c[m1:].view(torch.int16), tail.view(torch.int16)), (kind, sid)
+            P.check_sampled(c[m1:], a[m1:], True, f"native row split, exact tail {kind}")
+            x = from_bits(a, torch.bfloat16).to(DEV)
+            mul = P.mul if kind == "nv" else pk.mul_mxfp4_native
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                warm = mul(x, P.b, P.sp, P.gsd, m, n, k, sid)   # (scratch grown outside the capture)
+                st.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    out = mul(x, P.b, P.sp, P.gsd, m, n, k, sid)
+                out.zero_()
+                g.replay()
+                st.synchronize()
+            assert torch.equal(out.view(torch.int16), c.view(torch.int16)) and torch.equal(warm.view(torch.int16), c.view(torch.int16)), (kind, sid)
+            ran += 1
+            del c, bulk, tail, out, warm, g
+        del P
+        torch.cuda.empty_cache()
+    assert ran >= 2
+
+
 def test_bench_mlp_block_cells(pk):
     """The gated-MLP cells of bench.py (tools/benchlib.py MlpBlock: Llama-3-70B gate_up -> SiLU-mul -> down at M = 512, MXFP4
     weights) at full size, through the same calls: the exact path against the oracle (sampled columns of h, then `down` on the
