@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--klass", default="exact", choices=["exact", "native_mxfp8", "native_mxfp6", "native_mxfp4"],
                     help="the native classes (MXFP4 weights only: --families mx:bf16,mx:f16) fill csrc/tuned_native_gfx950.inc: tools/make_tuned_inc.py --native <out>.tune.txt")
     ap.add_argument("--only", default="", help="comma-separated substrings: keep the shapes whose description (model, layer, TP) contains one, e.g. llama3-70b,r01-r03")
+    ap.add_argument("--n-multiple", type=int, default=0, help="keep only shapes whose N is a multiple of this (e.g. 320: the shapes a 320-column tile divides)")
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--list", action="store_true", help="print the shape list and exit (no GPU needed)")
     args = ap.parse_args()
@@ -80,6 +81,8 @@ def main():
     if args.only:
         keys = [x for x in args.only.split(",") if x]
         todo = [nk for nk in todo if any(x in shapes.get(nk, "held-out") for x in keys)]
+    if args.n_multiple:
+        todo = [nk for nk in todo if nk[0] % args.n_multiple == 0]
     if args.list:
         for nk in todo:
             print(f"{nk[0]}x{nk[1]}  {shapes.get(nk, 'held-out')}")
