@@ -1444,8 +1444,11 @@ def test_bench_cells_parity(pk):
     assert max(pre) * max(nk[0] for nk in BL.LLAMA70B.values()) * 2 < 1 << 32 and max(pre) * max(nk[1] for nk in BL.LLAMA70B.values()) < 1 << 32
     ran = 0
     plan = every
+    acts = {}   # activations are a function of (M, K, dtype) only: drawn once per K (half of this test's time was CPU random numbers for 16375 x K matrices)
     for shape in BL.SHAPE_ORDER + BL.TP8_ORDER:
         n, k = BL.ALL_SHAPES[shape]
+        if any(key[1] != k for key in acts):
+            acts.clear()
         for w in ("nv", "mx"):
             cells = [c for c in plan if c["shape"] == shape and c["w"] == w]
             if not cells:
@@ -1453,7 +1456,9 @@ def test_bench_cells_parity(pk):
             P = FullSizeProblem(pk, w, n, k, 7 * n + k + len(w))
             for c in cells:
                 m, is_bf16, mode = c["M"], c["a"] == "bf16", c["mode"]
-                a = P.activations(m, is_bf16, 900 + m)
+                if (m, k, is_bf16) not in acts:
+                    acts[(m, k, is_bf16)] = P.activations(m, is_bf16, 900 + m)
+                a = acts[(m, k, is_bf16)]
                 # prefill cells: the GEMM runs at its full M; the oracle checks a sample of its rows (first / last m-tiles of every tile height the
                 # kernels use, the ragged tail, seeded others) x the sampled columns -- the CPU side of a 16375-row check would take minutes per cell
                 rows = sampled_rows(m)
