@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--ms", default="")
     ap.add_argument("--out", required=True)
     ap.add_argument("--table", default="")
+    ap.add_argument("--keep-untimed", action="store_true", help="a row whose kernel the session did not time (no longer a candidate at this M) stays, instead of being replaced by the session's winner")
     ap.add_argument("--klass", type=int, default=0, choices=[0, 8, 6, 4], help="0: the exact class; 8 / 6 / 4: the native class with MXFP8 / MXFP6 / MXFP4 activations")
     a = ap.parse_args()
     a.table = a.table or str(ROOT / "petit-kernel_amd" / "csrc" / ("tuned_native_gfx950.inc" if a.klass else "tuned_gfx950.inc"))
@@ -45,6 +46,9 @@ def main():
         old = [s for lo, hi, s in rows.get((at, bt, n, k), []) if lo <= m <= hi]
         o2 = c2[key].get(old[0]) if old else None
         if o2 is None:          # no row, or the row's kernel was not timed (its output check failed at this shape): take the session's winner
+            if old and a.keep_untimed:
+                kept += 1
+                continue
             out.append((at, bt, n, k, m, b2[key][0]))
             continue
         if key in c1 and c1[key].get(old[0]) is not None:
