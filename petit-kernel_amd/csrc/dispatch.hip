@@ -142,6 +142,18 @@ int tune_candidates(int a_type, int b_type, int klass, unsigned m, unsigned n, u
             if (guarded_splitk(e, sk, m, n, k, num_cus) == sk) // (a row must never name a split that choose_auto would take away again)
                 push(e, sk, false);
     }
+    // The table's own row for this problem is always a candidate: 110 rows of the 129 ... 4096 buckets name batched-decode kernels beyond the eight-m-block cap above (narrow N --
+    // 576 ... 3072 columns -- where W stays in L2 and many small workgroups fill the chip; measured winners of round 5), and a row the tuner cannot time can never be
+    // challenged by a newer kernel (tools/adopt_rows.py compares against the row's own time in the same session).
+    if (const uint64_t row = tuned_solution(current_device(), a_type, b_type, m, n, k, klass)) {
+        bool have = false;
+        for (int i = 0; i < count; ++i)
+            have |= ids[i] == row;
+        const SolutionEntry *e = have ? nullptr : find_explicit(fam, row);
+        const unsigned sk = solution_splitk(row);
+        if (e && sk && entry_class(*e) == klass && entry_fits(*e, m, k))
+            push(*e, sk, false);
+    }
     return count;
 }
 
