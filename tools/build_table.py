@@ -71,6 +71,7 @@ def main():
                     help="the native classes (MXFP4 weights only: --families mx:bf16,mx:f16) fill csrc/tuned_native_gfx950.inc: tools/make_tuned_inc.py --native <out>.tune.txt")
     ap.add_argument("--only", default="", help="comma-separated substrings: keep the shapes whose description (model, layer, TP) contains one, e.g. llama3-70b,r01-r03")
     ap.add_argument("--n-multiple", type=int, default=0, help="keep only shapes whose N is a multiple of this (e.g. 320: the shapes a 320-column tile divides)")
+    ap.add_argument("--k-not-multiple", type=int, default=0, help="keep only shapes whose K is NOT a multiple of this (1024: the shapes that need KS = 4 / 2 kernels)")
     ap.add_argument("--n-max", type=int, default=0, help="keep only shapes with N <= this (the narrow shapes whose rows name batched-decode kernels at prefill M)")
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--list", action="store_true", help="print the shape list and exit (no GPU needed)")
@@ -82,6 +83,8 @@ def main():
     if args.only:
         keys = [x for x in args.only.split(",") if x]
         todo = [nk for nk in todo if any(x in shapes.get(nk, "held-out") for x in keys)]
+    if args.k_not_multiple:
+        todo = [nk for nk in todo if nk[1] % args.k_not_multiple != 0]
     if args.n_max:
         todo = [nk for nk in todo if nk[0] <= args.n_max]
     if args.n_multiple:
